@@ -1,0 +1,241 @@
+/*
+ * ORACLE (test infrastructure only) — C half of the CPU restatement of the PythonCRT
+ * per-frame effect chain.  Nothing under pythoncrt_amd/ may link or load this file; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * These are the stages whose arithmetic the reference delegates to opencv-python-headless
+ * (requirements.txt:6, ">=4.8.0", not vendored under /root/reference).  They restate the
+ * published OpenCV 4.x algorithms; PARITY UNPINNED at this boundary (the reference holds no
+ * tests or golden vectors, and cv2 is not installable here).
+ *
+ *   orc_sepblur_f32      cv2.GaussianBlur call sites crt_filter.py:234 (triad softening, ksize (k,1))
+ *                        and :610 / :780 (bloom, ksize (k,k)), BORDER_REPLICATE.
+ *                        OpenCV: sepFilter2D with CV_32F intermediates; RowFilter / ColumnFilter
+ *                        accumulate tap 0 .. tap k-1 in order with fused multiply-add (the AVX2
+ *                        build's v_muladd).  OpenCV's symmetric-column variant and its IPP path
+ *                        reassociate the same sum; they differ from this by a few ulp.
+ *   orc_remap_bilinear_* cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) crt_filter.py:347.
+ *                        OpenCV: float maps are quantised to 1/32 px with cvRound
+ *                        (ties-to-even), integer part = >>5 saturated to short, weights from the
+ *                        32x32 bilinear table ((1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy fx in float),
+ *                        v = S00*w0 + S01*w1 + S10*w2 + S11*w3 evaluated left to right in the
+ *                        work type (float for CV_32F pixels, double for CV_64F pixels with float
+ *                        weights); taps outside the image contribute borderValue 0.
+ *   orc_resize_linear_f32 / orc_resize_nearest_f32
+ *                        cv2.resize call sites :582-583/:751-752 (INTER_NEAREST pixelate),
+ *                        :606-607/:776-777 (INTER_LINEAR fast bloom), :642/:812 (grain upsample).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off [-mfma]); fmaf() is exact either way.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* Separable correlation, BORDER_REPLICATE, interleaved channels.
+ * tmp must hold h*w*cn floats.  kx has nkx taps (anchor nkx/2), ky has nky taps. */
+int orc_sepblur_f32(const float* src, float* dst, float* tmp, int h, int w, int cn,
+                    const float* kx, int nkx, const float* ky, int nky)
+{
+    const int rx = nkx / 2, ry = nky / 2;
+    for (int y = 0; y < h; ++y) {
+        const float* srow = src + (size_t)y * w * cn;
+        float* trow = tmp + (size_t)y * w * cn;
+        for (int x = 0; x < w; ++x) {
+            for (int c = 0; c < cn; ++c) {
+                float s = 0.0f;
+                for (int k = 0; k < nkx; ++k) {
+                    int xx = clampi(x + k - rx, 0, w - 1);
+                    s = fmaf(srow[(size_t)xx * cn + c], kx[k], s);
+                }
+                trow[(size_t)x * cn + c] = s;
+            }
+        }
+    }
+    const size_t rowlen = (size_t)w * cn;
+    for (int y = 0; y < h; ++y) {
+        float* drow = dst + (size_t)y * rowlen;
+        for (size_t i = 0; i < rowlen; ++i) drow[i] = 0.0f;
+        for (int k = 0; k < nky; ++k) {
+            int yy = clampi(y + k - ry, 0, h - 1);
+            const float* trow = tmp + (size_t)yy * rowlen;
+            const float f = ky[k];
+            for (size_t i = 0; i < rowlen; ++i) drow[i] = fmaf(trow[i], f, drow[i]);
+        }
+    }
+    return 0;
+}
+
+/* cvRound for float: round half to even (SSE cvtss2si under the default MXCSR). */
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* Integer part / 5-bit fractions of the quantised map — exported so tests can check the
+ * GPU's tap indices bit-for-bit ("bit-exact for integer mask indexing"). */
+int orc_remap_quantise(const float* mapx, const float* mapy, int n, int32_t* ix, int32_t* iy, int32_t* fxy)
+{
+    for (int i = 0; i < n; ++i) {
+        int sx = cv_round_f(mapx[i] * 32.0f);
+        int sy = cv_round_f(mapy[i] * 32.0f);
+        ix[i] = sat_short(sx >> 5);
+        iy[i] = sat_short(sy >> 5);
+        fxy[i] = (sy & 31) * 32 + (sx & 31);
+    }
+    return 0;
+}
+
+#define REMAP_BODY(T, WT)                                                                      \
+    for (int y = 0; y < h; ++y) {                                                              \
+        for (int x = 0; x < w; ++x) {                                                          \
+            size_t m = (size_t)y * w + x;                                                      \
+            int sxq = cv_round_f(mapx[m] * 32.0f);                                             \
+            int syq = cv_round_f(mapy[m] * 32.0f);                                             \
+            int sx = sat_short(sxq >> 5), sy = sat_short(syq >> 5);                            \
+            float fx = (float)(sxq & 31) * (1.0f / 32.0f);                                     \
+            float fy = (float)(syq & 31) * (1.0f / 32.0f);                                     \
+            float wgt[4];                                                                      \
+            wgt[0] = (1.0f - fy) * (1.0f - fx);                                                \
+            wgt[1] = (1.0f - fy) * fx;                                                         \
+            wgt[2] = fy * (1.0f - fx);                                                         \
+            wgt[3] = fy * fx;                                                                  \
+            int in00 = (sx >= 0 && sx < w && sy >= 0 && sy < h);                               \
+            int in01 = (sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h);                       \
+            int in10 = (sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h);                       \
+            int in11 = (sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h);               \
+            for (int c = 0; c < cn; ++c) {                                                     \
+                WT v0 = in00 ? (WT)src[((size_t)sy * w + sx) * cn + c] : (WT)0;                \
+                WT v1 = in01 ? (WT)src[((size_t)sy * w + sx + 1) * cn + c] : (WT)0;            \
+                WT v2 = in10 ? (WT)src[((size_t)(sy + 1) * w + sx) * cn + c] : (WT)0;          \
+                WT v3 = in11 ? (WT)src[((size_t)(sy + 1) * w + sx + 1) * cn + c] : (WT)0;      \
+                WT r = v0 * wgt[0] + v1 * wgt[1] + v2 * wgt[2] + v3 * wgt[3];                  \
+                dst[m * cn + c] = (T)r;                                                        \
+            }                                                                                  \
+        }                                                                                      \
+    }
+
+int orc_remap_bilinear_f32(const float* src, float* dst, int h, int w, int cn,
+                           const float* mapx, const float* mapy)
+{
+    REMAP_BODY(float, float)
+    return 0;
+}
+
+int orc_remap_bilinear_f64(const double* src, double* dst, int h, int w, int cn,
+                           const float* mapx, const float* mapy)
+{
+    REMAP_BODY(double, double)
+    return 0;
+}
+
+/* cv2.resize INTER_NEAREST: sx = min(floor(dx * (sw/dw)), sw-1) with the ratio in double. */
+int orc_resize_nearest_f32(const float* src, int sh, int sw, float* dst, int dh, int dw, int cn)
+{
+    const double ifx = (double)sw / dw, ify = (double)sh / dh;
+    for (int y = 0; y < dh; ++y) {
+        int sy = (int)floor(y * ify);
+        if (sy > sh - 1) sy = sh - 1;
+        for (int x = 0; x < dw; ++x) {
+            int sx = (int)floor(x * ifx);
+            if (sx > sw - 1) sx = sw - 1;
+            memcpy(dst + ((size_t)y * dw + x) * cn, src + ((size_t)sy * sw + sx) * cn, sizeof(float) * cn);
+        }
+    }
+    return 0;
+}
+
+/* cv2.resize INTER_LINEAR for CV_32F.
+ * Exact 2x decimation (dw*2==sw && dh*2==sh) takes OpenCV's INTER_AREA fast path
+ * (resizeAreaFast: (a+b+c+d)*0.25f).  Otherwise: fx = (dx+0.5)*scale-0.5, sx=floor(fx),
+ * fx-=sx; sx<0 -> (0, fx=0); sx>=sw-1 -> (sw-1, fx=0); horizontal pass
+ * S[sx]*(1-fx) + S[sx+1]*fx, then vertical pass r0*(1-fy) + r1*fy, all float. */
+int orc_resize_linear_f32(const float* src, int sh, int sw, float* dst, int dh, int dw, int cn)
+{
+    if (dw * 2 == sw && dh * 2 == sh) {
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < cn; ++c) {
+                    const float* p = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+                    const float* q = p + (size_t)sw * cn;
+                    dst[((size_t)y * dw + x) * cn + c] = (p[0] + p[cn] + q[0] + q[cn]) * 0.25f;
+                }
+        return 0;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    float* xa = (float*)malloc(sizeof(float) * dw);
+    float* rows = (float*)malloc(sizeof(float) * 2 * (size_t)dw * cn);
+    if (!xofs || !xa || !rows) { free(xofs); free(xa); free(rows); return -1; }
+    for (int x = 0; x < dw; ++x) {
+        float fx = (float)((x + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[x] = sx; xa[x] = fx;
+    }
+    for (int y = 0; y < dh; ++y) {
+        float fy = (float)((y + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+        for (int r = 0; r < 2; ++r) {
+            const float* srow = src + (size_t)(r ? sy1 : sy) * sw * cn;
+            float* rr = rows + (size_t)r * dw * cn;
+            for (int x = 0; x < dw; ++x) {
+                int sx = xofs[x];
+                int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+                float a1 = xa[x], a0 = 1.0f - a1;
+                for (int c = 0; c < cn; ++c)
+                    rr[(size_t)x * cn + c] = srow[(size_t)sx * cn + c] * a0 + srow[(size_t)sx1 * cn + c] * a1;
+            }
+        }
+        const float b1 = fy, b0 = 1.0f - fy;
+        float* drow = dst + (size_t)y * dw * cn;
+        for (size_t i = 0; i < (size_t)dw * cn; ++i) drow[i] = rows[i] * b0 + rows[(size_t)dw * cn + i] * b1;
+    }
+    free(xofs); free(xa); free(rows);
+    return 0;
+}
+
+/* cv2.convertScaleAbs(alpha=255, beta=0): the 32f and 64f sources both go through the float
+ * work type (cvtabs_32f): u8 = saturate(cvRound(|(float)x * 255.0f + 0|)). */
+int orc_convert_scale_abs_f32(const float* src, uint8_t* dst, size_t n, float alpha)
+{
+    for (size_t i = 0; i < n; ++i) {
+        float v = fabsf(fmaf(src[i], alpha, 0.0f));
+        int r = cv_round_f(v);
+        dst[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    return 0;
+}
+
+int orc_convert_scale_abs_f64(const double* src, uint8_t* dst, size_t n, float alpha)
+{
+    for (size_t i = 0; i < n; ++i) {
+        float v = fabsf(fmaf((float)src[i], alpha, 0.0f));
+        int r = cv_round_f(v);
+        dst[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    return 0;
+}
+
+/* cv2.addWeighted(a, alpha, b, beta, 0): dst = fma(a, alpha, fma(b, beta, gamma)) in the
+ * array's own type (scalars narrowed to float for CV_32F). crt_filter.py:693. */
+int orc_add_weighted_f32(const float* a, float alpha, const float* b, float beta, float* dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = fmaf(a[i], alpha, fmaf(b[i], beta, 0.0f));
+    return 0;
+}
+
+int orc_add_weighted_f64(const double* a, double alpha, const double* b, double beta, double* dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = fma(a[i], alpha, fma(b[i], beta, 0.0));
+    return 0;
+}
+
+int orc_abi_version(void) { return 1; }
