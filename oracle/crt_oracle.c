@@ -130,10 +130,10 @@ int orc_remap_bilinear_f64(const double* src, double* dst, int h, int w, int cn,
     return 0;
 }
 
-/* cv2.resize INTER_NEAREST: sx = min(floor(dx * (sw/dw)), sw-1) with the ratio in double. */
+/* cv2.resize INTER_NEAREST (resizeNN): fx = dw/sw in double, ifx = 1/fx, sx = min(cvFloor(dx*ifx), sw-1). */
 int orc_resize_nearest_f32(const float* src, int sh, int sw, float* dst, int dh, int dw, int cn)
 {
-    const double ifx = (double)sw / dw, ify = (double)sh / dh;
+    const double ifx = 1.0 / ((double)dw / sw), ify = 1.0 / ((double)dh / sh);
     for (int y = 0; y < dh; ++y) {
         int sy = (int)floor(y * ify);
         if (sy > sh - 1) sy = sh - 1;

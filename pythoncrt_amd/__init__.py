@@ -1,0 +1,10 @@
+"""pythoncrt_amd — MI355X-native per-frame CRT effect chain behind PythonCRT's own API.
+
+    from pythoncrt_amd import apply_crt_effect, apply_static_effects, make_triad_mask, make_vignette
+
+See DESIGN.md (path, kernels, roofline) and INTEGRATION.md (how the reference binds to it).
+"""
+from .effects import (TriadMask, VignetteMask, apply_crt_effect, apply_static_effects, make_triad_mask,
+                      make_vignette)
+
+__all__ = ["TriadMask", "VignetteMask", "apply_crt_effect", "apply_static_effects", "make_triad_mask", "make_vignette"]

@@ -1,0 +1,441 @@
+// crtfx.hip — libcrtfx.so: C-ABI (include/crtfx.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/build.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "crtfx.h"
+#include "crtfx_kernels.hip.h"
+
+using namespace crtfx;
+
+namespace {
+
+constexpr int MAX_RADIUS = 64;   // ring of (NB + 2R) rows must fit LDS next to staging and LUTs
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct crtfx_ctx {
+    int device = 0;
+    int H = 0, W = 0;
+    int pix_fmt = CRTFX_PIX_U8;
+    bool params_set = false;
+    KParams kp{};
+    DevBuf taps, triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
+    float* pre = nullptr;            // H*W*3 float32 pre-warp scratch
+    int seg_rows = 0;                // rows per k_phosphor block
+    std::string err;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev[2];   // pairs (start, stop) per launch, per kernel class
+    size_t ev_used[2] = {0, 0};
+};
+
+namespace {
+
+int fail(crtfx_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) return fail((c), CRTFX_E_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+int upload(crtfx_ctx* c, DevBuf& b, const void* host, size_t bytes) {
+    if (!host || bytes == 0) return CRTFX_OK;
+    if (b.bytes < bytes) {
+        if (b.p) HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+        HIP_TRY(c, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    HIP_TRY(c, hipMemcpy(b.p, host, bytes, hipMemcpyHostToDevice));
+    return CRTFX_OK;
+}
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+
+uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+void noise_keys(uint64_t seed, uint64_t frame, uint32_t& k0, uint32_t& k1) {
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    const uint32_t f0 = (uint32_t)frame, f1 = (uint32_t)(frame >> 32);
+    k0 = mix32(s0 ^ mix32(f0 + 0x9E3779B9U) ^ mix32(f1 + 0x85EBCA6BU));
+    k1 = mix32(s1 + 0xC2B2AE35U + mix32(k0 ^ f0));
+}
+
+KFrame make_kframe(const void* in, const crtfx_frame* f) {
+    KFrame k{};
+    k.in = static_cast<const uint8_t*>(in);
+    if (f) {
+        k.scan_row = f->scan_row_dev;
+        k.scan_plane = f->scan_plane_dev;
+        k.noise_plane = f->noise_plane_dev;
+        k.flicker = f->flicker_factor;
+        noise_keys(f->noise_seed, f->frame_index, k.key0, k.key1);
+    } else {
+        k.flicker = 1.0;
+        noise_keys(0, 0, k.key0, k.key1);
+    }
+    return k;
+}
+
+size_t phosphor_lds_bytes(int R) {
+    const int pad = (R + 3) & ~3;
+    const int SWP = TW + 2 * pad;
+    const size_t floats = (size_t)NB * 3 * SWP + (size_t)(NB + 2 * R) * 3 * TW + (size_t)NB * 3 * TW + 2 * LUT_STRIDE;
+    return floats * sizeof(float);
+}
+
+struct ProfScope {
+    crtfx_ctx* c; int k; hipStream_t s; hipEvent_t stop = nullptr;
+    ProfScope(crtfx_ctx* c_, int k_, hipStream_t s_) : c(c_), k(k_), s(s_) {
+        if (!c->prof) return;
+        auto& v = c->ev[k];
+        size_t& u = c->ev_used[k];
+        if (u + 2 > v.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            v.push_back(a); v.push_back(b);
+        }
+        (void)hipEventRecord(v[u], s);
+        stop = v[u + 1];
+        u += 2;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
+};
+
+template <int RT>
+void launch_phosphor_t(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    const int strips = (c->W + TW - 1) / TW;
+    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
+    const size_t lds = phosphor_lds_bytes(c->kp.R);
+    hipLaunchKernelGGL((k_phosphor<RT>), dim3(strips, segs), dim3(K1_THREADS), lds, s, c->kp, kf, ko, c->seg_rows);
+}
+
+void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    ProfScope ps(c, 0, s);
+    switch (c->kp.R) {
+        case 4: launch_phosphor_t<4>(c, kf, ko, s); break;    // sigma 1.2 / 1.5 (CLI default sigma, BASELINE config 2)
+        case 9: launch_phosphor_t<9>(c, kf, ko, s); break;    // sigma 3 (BASELINE config 3)
+        default: launch_phosphor_t<-1>(c, kf, ko, s); break;
+    }
+}
+
+// The whole chain for one frame.  ko describes the FINAL outputs.
+int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipStream_t s) {
+    if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
+    if (!in) return fail(c, CRTFX_E_INVALID, "frame pointer is NULL");
+    const uint32_t fl = c->kp.flags;
+    if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev)))
+        return fail(c, CRTFX_E_INVALID, "scanlines are on but the frame record carries no scan_row_dev / scan_plane_dev");
+    if (f && (f->overlay_rgba_dev || f->glitch_offs_dev))
+        return fail(c, CRTFX_E_UNSUPPORTED, "text overlay / glitch are not built yet (SURVEY 8f rows 1-2)");
+    if ((fl & CRTFX_F_NOISE) && c->kp.grain > 1)
+        return fail(c, CRTFX_E_UNSUPPORTED, "grain_size > 1 is not built yet (SURVEY 8f row 3)");
+    const KFrame kf = make_kframe(in, f);
+    const bool warp = (fl & CRTFX_F_WARP) != 0;
+    KOut k1 = ko;
+    if (warp) { k1 = KOut{}; k1.pre = c->pre; }
+    if (fl & CRTFX_F_BLOOM) {
+        launch_phosphor(c, kf, k1, s);
+    } else {
+        ProfScope ps(c, 0, s);
+        dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
+        hipLaunchKernelGGL(k_point, grid, dim3(256), 0, s, c->kp, kf, k1);
+    }
+    if (warp) {
+        ProfScope ps(c, 1, s);
+        dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
+        hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, s, c->kp, (const float*)c->pre, ko, 0);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int check_blend(crtfx_ctx* c, int blend, double p, const float* state) {
+    if (blend != CRTFX_BLEND_NONE && blend != CRTFX_BLEND_RENDER && blend != CRTFX_BLEND_PREVIEW)
+        return fail(c, CRTFX_E_INVALID, "unknown blend mode %d", blend);
+    if (blend != CRTFX_BLEND_NONE && !state) return fail(c, CRTFX_E_INVALID, "blend needs state_inout_dev");
+    if (blend != CRTFX_BLEND_NONE && !(p > 0.0 && p < 1.0)) return fail(c, CRTFX_E_INVALID, "persistence %g outside (0,1)", p);
+    return CRTFX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crtfx_version(void) { return CRTFX_ABI_VERSION; }
+
+const char* crtfx_last_error(const crtfx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out_ctx) {
+    if (!out_ctx) return CRTFX_E_INVALID;
+    *out_ctx = nullptr;
+    if (height <= 0 || width <= 0 || height > 32767 || width > 32767) return CRTFX_E_INVALID;
+    if (pix_fmt != CRTFX_PIX_U8) return CRTFX_E_UNSUPPORTED;   // CRTFX_PIX_F16: BASELINE config 5, not built yet
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CRTFX_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return CRTFX_E_HIP;
+    crtfx_ctx* c = new (std::nothrow) crtfx_ctx();
+    if (!c) return CRTFX_E_NOMEM;
+    c->device = device; c->H = height; c->W = width; c->pix_fmt = pix_fmt;
+    if (hipMalloc((void**)&c->pre, (size_t)height * width * 3 * sizeof(float)) != hipSuccess) { delete c; return CRTFX_E_NOMEM; }
+    // rows per k_phosphor block: aim at >= ~4 blocks per CU over 256 CUs, but keep the vertical
+    // halo (2R extra H-pass rows per block) small: never shorter than 64 rows.
+    const int strips = (width + TW - 1) / TW;
+    int segs = (1024 + strips - 1) / strips;
+    int seg = (height + segs - 1) / segs;
+    if (seg < 64) seg = 64;
+    seg = ((seg + NB - 1) / NB) * NB;
+    if (seg > height) seg = ((height + NB - 1) / NB) * NB;
+    c->seg_rows = seg;
+    *out_ctx = c;
+    return CRTFX_OK;
+}
+
+int crtfx_destroy(crtfx_ctx* c) {
+    if (!c) return CRTFX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&c->taps, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap}) free_buf(*b);
+    if (c->pre) (void)hipFree(c->pre);
+    for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    delete c;
+    return CRTFX_OK;
+}
+
+int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
+    if (!c || !p) return CRTFX_E_INVALID;
+    if (p->size != sizeof(crtfx_params)) return fail(c, CRTFX_E_INVALID, "crtfx_params.size %u != %zu", p->size, sizeof(crtfx_params));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());   // tables may be in use by enqueued work
+    const uint32_t fl = p->flags;
+    const int H = c->H, W = c->W;
+    if (fl & CRTFX_F_BLOOM_FAST) return fail(c, CRTFX_E_UNSUPPORTED, "fast (half-res bilinear) bloom is not built yet (SURVEY 8f row 3)");
+    if (fl & CRTFX_F_BLOOM) {
+        if (p->bloom_radius < 0 || p->bloom_radius > MAX_RADIUS)
+            return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d outside [0,%d] (sigma up to ~21)", p->bloom_radius, MAX_RADIUS);
+        if (!p->bloom_taps) return fail(c, CRTFX_E_INVALID, "bloom on but bloom_taps NULL");
+    }
+    if ((fl & CRTFX_F_TRIAD) && !p->triad_row && !p->triad_full_dev) return fail(c, CRTFX_E_INVALID, "triad on but no mask");
+    if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT) && !(p->lut_g && p->lut_inv)) return fail(c, CRTFX_E_INVALID, "triad LUT path needs lut_g/lut_inv");
+    if ((fl & CRTFX_F_VIGNETTE) && !p->vignette_full_dev && !(p->vig_nx2 && p->vig_ny2)) return fail(c, CRTFX_E_INVALID, "vignette on but no tables");
+    if ((fl & CRTFX_F_WARP) && !(p->warp_xhat && p->warp_yhat)) return fail(c, CRTFX_E_INVALID, "warp on but no axis tables");
+    if ((fl & CRTFX_F_PIXELATE) && !(p->pix_xmap && p->pix_ymap)) return fail(c, CRTFX_E_INVALID, "pixelate on but no index maps");
+    if (p->aberration_px < -8 || p->aberration_px > 8) return fail(c, CRTFX_E_INVALID, "aberration_px %d outside [-8,8] (ref:1230)", p->aberration_px);
+
+    int rc;
+    const int R = (fl & CRTFX_F_BLOOM) ? p->bloom_radius : 0;
+    if ((rc = upload(c, c->taps, p->bloom_taps, (fl & CRTFX_F_BLOOM) ? (2 * R + 1) * sizeof(float) : 0))) return rc;
+    if ((rc = upload(c, c->triad_row, p->triad_row, (size_t)W * 3 * sizeof(float)))) return rc;
+    if ((rc = upload(c, c->lut_g, p->lut_g, LUT_N * sizeof(float)))) return rc;
+    if ((rc = upload(c, c->lut_inv, p->lut_inv, LUT_N * sizeof(float)))) return rc;
+    if ((rc = upload(c, c->nx2, p->vig_nx2, (size_t)W * sizeof(double)))) return rc;
+    if ((rc = upload(c, c->ny2, p->vig_ny2, (size_t)H * sizeof(double)))) return rc;
+    if ((rc = upload(c, c->xhat, p->warp_xhat, (size_t)W * sizeof(float)))) return rc;
+    if ((rc = upload(c, c->yhat, p->warp_yhat, (size_t)H * sizeof(float)))) return rc;
+    if ((rc = upload(c, c->xmap, p->pix_xmap, (size_t)W * sizeof(int32_t)))) return rc;
+    if ((rc = upload(c, c->ymap, p->pix_ymap, (size_t)H * sizeof(int32_t)))) return rc;
+
+    KParams k{};
+    k.H = H; k.W = W; k.flags = fl; k.ab = p->aberration_px; k.R = R; k.grain = p->grain_size;
+    k.sat = p->saturation; k.r_gain = p->r_gain; k.b_gain = p->b_gain;
+    k.contrast = p->contrast; k.brightness = p->brightness; k.inv_gamma = p->inv_gamma;
+    k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
+    k.noise_scale = p->noise_scale; k.warp_k = p->warp_k; k.cx = p->warp_cx; k.cy = p->warp_cy;
+    k.vig_strength = p->vignette_strength;
+    k.taps = (const float*)c->taps.p;
+    k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
+    k.triad_full = p->triad_full_dev;
+    k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
+    k.vig_nx2 = (const double*)c->nx2.p; k.vig_ny2 = (const double*)c->ny2.p;
+    k.vig_full = p->vignette_full_dev;
+    k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
+    k.xmap = (const int*)c->xmap.p; k.ymap = (const int*)c->ymap.p;
+    if ((fl & CRTFX_F_BLOOM) && R == 0) k.flags |= 0;   // ksize 1: GaussianBlur copies; handled by taps = [1]
+    c->kp = k;
+    c->params_set = true;
+
+    if (fl & CRTFX_F_BLOOM) {
+        const size_t lds = phosphor_lds_bytes(R);
+        if (lds > 160 * 1024) return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d needs %zu B of LDS", R, lds);
+        // opt in to > 64 KiB of dynamic LDS
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    return CRTFX_OK;
+}
+
+int crtfx_apply_static(crtfx_ctx* c, const void* frame_dev, float* out_float_dev, const crtfx_frame* frame, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (!out_float_dev) return fail(c, CRTFX_E_INVALID, "out_float_dev is NULL");
+    KOut ko{};
+    ko.out_f32 = out_float_dev;
+    ko.blend = CRTFX_BLEND_NONE;
+    return run_chain(c, frame_dev, frame, ko, (hipStream_t)stream);
+}
+
+int crtfx_apply(crtfx_ctx* c, const void* frame_dev, void* out_pix_dev, float* state_inout_dev, float* out_float_dev,
+                int blend, double persistence, const crtfx_frame* frame, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    int rc = check_blend(c, blend, persistence, state_inout_dev);
+    if (rc) return rc;
+    if (!out_pix_dev && !state_inout_dev && !out_float_dev) return fail(c, CRTFX_E_INVALID, "no output requested");
+    KOut ko{};
+    ko.out_u8 = static_cast<uint8_t*>(out_pix_dev);
+    ko.state = state_inout_dev;
+    ko.out_f32 = out_float_dev;
+    ko.blend = blend;
+    ko.p = persistence; ko.q = 1.0 - persistence;
+    return run_chain(c, frame_dev, frame, ko, (hipStream_t)stream);
+}
+
+int crtfx_blend_quantise(crtfx_ctx* c, const float* static_dev, float* state_inout_dev, void* out_pix_dev, int blend,
+                         double persistence, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (!static_dev) return fail(c, CRTFX_E_INVALID, "static_dev is NULL");
+    int rc = check_blend(c, blend, persistence, state_inout_dev);
+    if (rc) return rc;
+    KOut ko{};
+    ko.out_u8 = static_cast<uint8_t*>(out_pix_dev);
+    ko.state = state_inout_dev;
+    ko.blend = blend;
+    ko.p = persistence; ko.q = 1.0 - persistence;
+    ProfScope ps(c, 1, (hipStream_t)stream);
+    dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
+    hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, static_dev, (const float*)nullptr, 0.0, ko, 0);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_halo_correct_quantise(crtfx_ctx* c, const float* local_dev, const float* carry_in_dev, double coeff,
+                                float* state_out_dev, void* out_pix_dev, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (!local_dev || !carry_in_dev) return fail(c, CRTFX_E_INVALID, "local_dev / carry_in_dev is NULL");
+    KOut ko{};
+    ko.out_u8 = static_cast<uint8_t*>(out_pix_dev);
+    ko.state = state_out_dev;
+    ko.blend = CRTFX_BLEND_NONE;
+    ProfScope ps(c, 1, (hipStream_t)stream);
+    dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
+    hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, local_dev, carry_in_dev, coeff, ko, 1);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stride_bytes, void* out_base,
+                        size_t out_stride_bytes, int n, const crtfx_frame* frames, float* state_inout_dev,
+                        double persistence, int first_has_state, float* local_states_base, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (n < 0 || !frames_base || (!out_base && !local_states_base)) return fail(c, CRTFX_E_INVALID, "bad batch arguments");
+    if (persistence > 0.0 && !state_inout_dev) return fail(c, CRTFX_E_INVALID, "persistence > 0 needs state_inout_dev");
+    const size_t state_elems = (size_t)c->H * c->W * 3;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* in = static_cast<const uint8_t*>(frames_base) + (size_t)i * frame_stride_bytes;
+        KOut ko{};
+        ko.out_u8 = out_base ? static_cast<uint8_t*>(out_base) + (size_t)i * out_stride_bytes : nullptr;
+        ko.p = persistence; ko.q = 1.0 - persistence;
+        if (persistence > 0.0) {
+            ko.state = state_inout_dev;
+            ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE;
+        } else {
+            ko.state = nullptr;
+            ko.blend = CRTFX_BLEND_NONE;
+        }
+        int rc = run_chain(c, in, frames ? &frames[i] : nullptr, ko, (hipStream_t)stream);
+        if (rc) return rc;
+        if (local_states_base) {
+            if (!ko.state) return fail(c, CRTFX_E_INVALID, "local_states_base needs persistence > 0");
+            HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)i * state_elems, ko.state, state_elems * sizeof(float),
+                                      hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        }
+    }
+    return CRTFX_OK;
+}
+
+int crtfx_noise_plane(crtfx_ctx* c, uint64_t seed, uint64_t frame_index, float* out_dev, void* stream) {
+    if (!c || !out_dev) return CRTFX_E_INVALID;
+    uint32_t k0, k1;
+    noise_keys(seed, frame_index, k0, k1);
+    const int n = c->H * c->W;
+    hipLaunchKernelGGL(k_noise_plane, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, k0, k1, out_dev);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_warp_map(crtfx_ctx* c, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_dev, void* stream) {
+    if (!c || !ix_dev || !iy_dev || !fxy_dev) return CRTFX_E_INVALID;
+    if (!c->params_set || !(c->kp.flags & CRTFX_F_WARP)) return fail(c, CRTFX_E_INVALID, "warp is not enabled in the current params");
+    hipLaunchKernelGGL(k_warp_map, dim3((c->W + 255) / 256, c->H), dim3(256), 0, (hipStream_t)stream, c->kp, ix_dev, iy_dev, fxy_dev);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, const float* taps, int ntaps) {
+    if (!row_in || !row_out || !taps || w <= 0 || cn <= 0 || ntaps <= 0 || !(ntaps & 1)) return CRTFX_E_INVALID;
+    const int r = ntaps / 2;
+    for (int x = 0; x < w; ++x)
+        for (int ch = 0; ch < cn; ++ch) {
+            float s = 0.0f;
+            for (int k = 0; k < ntaps; ++k) {
+                int xx = x + k - r;
+                xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+                s = __builtin_fmaf(row_in[(size_t)xx * cn + ch], taps[k], s);
+            }
+            row_out[(size_t)x * cn + ch] = s;
+        }
+    return CRTFX_OK;
+}
+
+int crtfx_profile_enable(crtfx_ctx* c, int on) {
+    if (!c) return CRTFX_E_INVALID;
+    c->prof = on != 0;
+    c->ev_used[0] = c->ev_used[1] = 0;
+    return CRTFX_OK;
+}
+
+int crtfx_profile_read(crtfx_ctx* c, int kernel, double* mean_ms, int* launches) {
+    if (!c || kernel < 0 || kernel > 1 || !mean_ms || !launches) return CRTFX_E_INVALID;
+    const size_t u = c->ev_used[kernel];
+    double total = 0.0;
+    int cnt = 0;
+    for (size_t i = 0; i + 1 < u; i += 2) {
+        HIP_TRY(c, hipEventSynchronize(c->ev[kernel][i + 1]));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[kernel][i], c->ev[kernel][i + 1]));
+        total += ms; ++cnt;
+    }
+    *mean_ms = cnt ? total / cnt : 0.0;
+    *launches = cnt;
+    c->ev_used[kernel] = 0;
+    return CRTFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,575 @@
+// crtfx_kernels.hip.h — gfx950 device code of the CRT effect chain.
+//
+// Chain order and arithmetic follow crt_filter.py (ref:LINE) stage by stage; every float
+// operation is written out in the reference's evaluation order and the translation unit is
+// built with -ffp-contract=off, so the only fused multiply-adds are the explicit fmaf() chains
+// of the separable blur (the accumulation form OpenCV's filter engine uses).  Tables that the
+// reference gets from numpy transcendental calls (LUTs, scanline row gains, Gaussian taps,
+// flicker factor) arrive precomputed from the host.
+//
+// Launch structure per frame:
+//   k_phosphor   u8 frame -> [a1 normalise, a2 aberration, a3 pixelate map, a4 grade] ->
+//                a5 separable Gaussian bloom through LDS (column strips, H-pass ring) ->
+//                a7 triad, a8 scanlines, a9 vignette, a10 flicker, a11 grain
+//                -> float32 pre-warp image (or, with no warp, straight to the commit epilogue)
+//   k_point      the same chain with bloom off: purely pointwise, no LDS staging
+//   k_warp       a12 barrel-warp bilinear gather (+ a14 persistence, a15 quantise)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "crtfx.h"
+
+namespace crtfx {
+
+// ---------------------------------------------------------------------------------------
+// kernel-side parameter blocks (passed by value as kernel arguments)
+// ---------------------------------------------------------------------------------------
+struct KParams {
+    int H, W;
+    uint32_t flags;
+    int ab;
+    int R;
+    int grain;
+    float sat, r_gain, b_gain, contrast, brightness, inv_gamma;
+    float thr, thr_den, bloom_strength;
+    float noise_scale;
+    float warp_k, cx, cy;
+    double vig_strength;
+    const float* __restrict__ taps;
+    const float* __restrict__ triad_row;
+    const float* __restrict__ triad_full;
+    const float* __restrict__ lut_g;
+    const float* __restrict__ lut_inv;
+    const double* __restrict__ vig_nx2;
+    const double* __restrict__ vig_ny2;
+    const double* __restrict__ vig_full;
+    const float* __restrict__ xhat;
+    const float* __restrict__ yhat;
+    const int* __restrict__ xmap;
+    const int* __restrict__ ymap;
+};
+
+struct KFrame {
+    const uint8_t* __restrict__ in;
+    const float* __restrict__ scan_row;
+    const float* __restrict__ scan_plane;
+    const float* __restrict__ noise_plane;
+    double flicker;
+    uint32_t key0, key1;
+};
+
+struct KOut {
+    float* pre;          // pre-warp float image (two-kernel path) or nullptr
+    float* out_f32;      // final static float image or nullptr
+    uint8_t* out_u8;     // quantised frame or nullptr
+    float* state;        // persistence state in/out or nullptr
+    int blend;           // crtfx_blend
+    double p, q;         // persistence, 1 - persistence (double, as python computes them)
+};
+
+constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
+constexpr int NB = 8;             // rows per H-pass block / register-blocked V outputs
+constexpr int K1_THREADS = 192;   // 3 wavefronts: wave w owns channel w in the V pass
+constexpr int LUT_N = 1025;
+constexpr int LUT_STRIDE = 1028;
+
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ double clip01(double v) { return fmin(fmax(v, 0.0), 1.0); }
+
+// a1 — u8/255.0 correctly rounded without the full division sequence: one Newton correction
+// of the reciprocal product; exhaustively equal to IEEE division for 0..255 (tests/test_parity_gpu).
+__device__ __forceinline__ float norm_u8(uint32_t u) {
+    const float f = (float)u;
+    const float rcp = 1.0f / 255.0f;
+    const float q = f * rcp;
+    const float r = fmaf(-q, 255.0f, f);
+    return fmaf(r, rcp, q);
+}
+
+__device__ __forceinline__ int wrap(int x, int W) {
+    x %= W;
+    return x < 0 ? x + W : x;
+}
+
+// a1+a2(+a3): one RGB sample of the aberrated (and pixelated) float image; (y, x) in range.
+// ref:569-584 — R'[x] = R[(x-d) mod W], B'[x] = B[(x+d) mod W]; pixelate = index maps.
+__device__ __forceinline__ void fetch_rgb(const KParams& P, const uint8_t* __restrict__ in, int y, int x,
+                                          float& r, float& g, float& b) {
+    if (P.flags & CRTFX_F_PIXELATE) { x = P.xmap[x]; y = P.ymap[y]; }
+    const uint8_t* row = in + (size_t)y * P.W * 3;
+    int xr = x, xb = x;
+    if (P.ab != 0) { xr = wrap(x - P.ab, P.W); xb = wrap(x + P.ab, P.W); }
+    r = norm_u8(row[xr * 3 + 0]);
+    g = norm_u8(row[x * 3 + 1]);
+    b = norm_u8(row[xb * 3 + 2]);
+}
+
+// a4 — apply_color_adjustments (ref:279-305), float32 throughout.
+__device__ __forceinline__ void grade(const KParams& P, float& r, float& g, float& b) {
+    if (P.flags & CRTFX_F_SATURATION) {
+        const float luma = (0.2126f * r + 0.7152f * g) + 0.0722f * b;
+        r = clip01(luma + (r - luma) * P.sat);
+        g = clip01(luma + (g - luma) * P.sat);
+        b = clip01(luma + (b - luma) * P.sat);
+    }
+    if (P.flags & CRTFX_F_TEMPERATURE) {
+        r = clip01(r * P.r_gain);
+        b = clip01(b * P.b_gain);
+    }
+    if (P.flags & CRTFX_F_BRIGHTCON) {
+        r = clip01(((r - 0.5f) * P.contrast + 0.5f) + P.brightness);
+        g = clip01(((g - 0.5f) * P.contrast + 0.5f) + P.brightness);
+        b = clip01(((b - 0.5f) * P.contrast + 0.5f) + P.brightness);
+    }
+    if (P.flags & CRTFX_F_GAMMA) {
+        r = clip01(powf(r, P.inv_gamma));
+        g = clip01(powf(g, P.inv_gamma));
+        b = clip01(powf(b, P.inv_gamma));
+    }
+}
+
+// bloom source (ref:601-604)
+__device__ __forceinline__ float bloom_src(const KParams& P, float v) {
+    if (P.flags & CRTFX_F_BLOOM_THR) return clip01((v - P.thr) / P.thr_den);
+    return v;
+}
+
+// a11 RNG: counter-based (stateless) hash -> Box-Muller.  One N(0,1) per pixel, shared by the
+// three channels (ref:646-647).  Keyed by (seed, frame) through key0/key1.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float grain_normal(uint32_t key0, uint32_t key1, uint32_t idx) {
+    const uint32_t a = lowbias32(idx ^ key0);
+    const uint32_t b = lowbias32((a + 0x9E3779B9U) ^ key1);
+    const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-08f;   // (0, 1]
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;          // [0, 1)
+    const float l2 = __builtin_amdgcn_logf(u1);                          // log2
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * l2); // sqrt(-2 ln u1)
+    return rad * __builtin_amdgcn_cosf(u2);                              // cos(2 pi u2)
+}
+
+// a7..a11 — from the post-bloom image to the pre-warp image.  The reference's image is float32
+// up to the scanline multiply and float64 from the vignette / flicker multiply on (NumPy
+// promotion); T mirrors that so the values agree before the single final narrowing.
+template <typename T>
+__device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, int y, int x,
+                                           float r, float g, float b,
+                                           const float* __restrict__ lut_g, const float* __restrict__ lut_inv,
+                                           T& o0, T& o1, T& o2) {
+    // a7 — _apply_triad_mask (ref:238-263)
+    if (P.flags & CRTFX_F_TRIAD) {
+        const float* m = P.triad_full ? P.triad_full + ((size_t)y * P.W + x) * 3 : P.triad_row + x * 3;
+        const float m0 = m[0], m1 = m[1], m2 = m[2];
+        if (P.flags & CRTFX_F_TRIAD_LUT) {
+            int i0 = min(max((int)(clip01(r) * 1024.0f), 0), 1024);
+            int i1 = min(max((int)(clip01(g) * 1024.0f), 0), 1024);
+            int i2 = min(max((int)(clip01(b) * 1024.0f), 0), 1024);
+            const float l0 = lut_g[i0], l1 = lut_g[i1], l2 = lut_g[i2];
+            float q0 = l0 * m0, q1 = l1 * m1, q2 = l2 * m2;
+            if (P.flags & CRTFX_F_TRIAD_LUMA) {
+                const float yb = (0.2126f * l0 + 0.7152f * l1) + 0.0722f * l2;
+                const float ya = (0.2126f * q0 + 0.7152f * q1) + 0.0722f * q2;
+                float ratio = yb / fmaxf(ya, 1e-6f);
+                ratio = fminf(fmaxf(ratio, 0.5f), 2.0f);
+                q0 *= ratio; q1 *= ratio; q2 *= ratio;
+            }
+            i0 = min(max((int)(clip01(q0) * 1024.0f), 0), 1024);
+            i1 = min(max((int)(clip01(q1) * 1024.0f), 0), 1024);
+            i2 = min(max((int)(clip01(q2) * 1024.0f), 0), 1024);
+            r = clip01(lut_inv[i0]); g = clip01(lut_inv[i1]); b = clip01(lut_inv[i2]);
+        } else {
+            r = clip01(r * m0); g = clip01(g * m1); b = clip01(b * m2);
+        }
+    }
+    // a8 — scanlines (ref:617-624)
+    if (P.flags & CRTFX_F_SCANLINES) {
+        const float sl = F.scan_plane ? F.scan_plane[(size_t)y * P.W + x] : F.scan_row[y];
+        r = clip01(r * sl); g = clip01(g * sl); b = clip01(b * sl);
+    }
+    T v0 = (T)r, v1 = (T)g, v2 = (T)b;
+    // a9 — vignette (ref:266-276, 626-628); float64 mask
+    if (P.flags & CRTFX_F_VIGNETTE) {
+        double v;
+        if (P.vig_full) v = P.vig_full[(size_t)y * P.W + x];
+        else            v = 1.0 - P.vig_strength * clip01(P.vig_nx2[x] + P.vig_ny2[y]);
+        v0 = (T)clip01((double)v0 * v); v1 = (T)clip01((double)v1 * v); v2 = (T)clip01((double)v2 * v);
+    }
+    // a10 — flicker (ref:630-633); np.float64 factor
+    if (P.flags & CRTFX_F_FLICKER) {
+        v0 = (T)clip01((double)v0 * F.flicker); v1 = (T)clip01((double)v1 * F.flicker); v2 = (T)clip01((double)v2 * F.flicker);
+    }
+    // a11 — grain (ref:635-647): float32 noise * float32 scale, added in the image dtype
+    if (P.flags & CRTFX_F_NOISE) {
+        const uint32_t idx = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+        const float z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
+        const float n = z * P.noise_scale;
+        v0 = clip01(v0 + (T)n); v1 = clip01(v1 + (T)n); v2 = clip01(v2 + (T)n);
+    }
+    o0 = v0; o1 = v1; o2 = v2;
+}
+
+__device__ __forceinline__ bool promotes(const KParams& P) {
+    return (P.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
+}
+
+// a15 — cv2.convertScaleAbs(alpha=255): saturate(round-half-even(|(float)x * 255|))
+__device__ __forceinline__ uint32_t quant_u8(float v) {
+    const float s = fabsf(v * 255.0f);
+    const int r = (int)rintf(s);
+    return (uint32_t)min(max(r, 0), 255);
+}
+
+// Store 64 consecutive pixels' RGB bytes of one row from one wavefront.  Lane l holds pixel
+// (x0 + l) packed as r | g<<8 | b<<16.  When the row segment is dword-aligned the wavefront
+// re-packs through lane shuffles and lanes 0..47 store one dword each (192 contiguous bytes);
+// otherwise each lane stores its 3 bytes.
+__device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t row_byte0, int lane,
+                                             int valid_px, uint32_t packed) {
+    const bool aligned = ((row_byte0 & 3) == 0);   // wave-uniform
+    if (aligned) {
+        const int j = lane;                // dword index in the 192-byte segment
+        const int a = (4 * j) / 3;         // first contributing pixel
+        const int o = (4 * j) - 3 * a;     // byte offset inside that pixel (0..2)
+        const uint32_t lo = __shfl(packed, a & 63);
+        const uint32_t hi = __shfl(packed, (a + 1) & 63);
+        // bytes lo[o..2] then hi[0..2]: (3 - o) + 3 >= 4 bytes, take the first four
+        const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 24);
+        const uint32_t dw = (uint32_t)(v >> (8 * o));
+        const int nbytes = valid_px * 3;
+        if (j < 48) {
+            if (4 * j + 4 <= nbytes) {
+                *reinterpret_cast<uint32_t*>(out + row_byte0 + 4 * j) = dw;
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (4 * j + k < nbytes) out[row_byte0 + 4 * j + k] = (uint8_t)(dw >> (8 * k));
+            }
+        }
+    } else if (lane < valid_px) {
+        uint8_t* p = out + row_byte0 + (size_t)lane * 3;
+        p[0] = (uint8_t)packed; p[1] = (uint8_t)(packed >> 8); p[2] = (uint8_t)(packed >> 16);
+    }
+}
+
+// a14 + a15 — commit epilogue shared by every kernel that produces final pixels.
+// T is the reference's image dtype at this point (double once promoted).
+// Returns the packed u8 pixel; stores the float outputs itself.
+template <typename T>
+__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, size_t pix, T v0, T v1, T v2) {
+    if (O.out_f32) {
+        float* p = O.out_f32 + pix * 3;
+        p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2;
+    }
+    if (O.blend == CRTFX_BLEND_RENDER) {           // ref:1092
+        const float* s = O.state + pix * 3;
+        const T p = (T)O.p, q = (T)O.q;
+        v0 = clip01(p * (T)s[0] + q * v0); v1 = clip01(p * (T)s[1] + q * v1); v2 = clip01(p * (T)s[2] + q * v2);
+    } else if (O.blend == CRTFX_BLEND_PREVIEW) {   // ref:693 addWeighted = fma(prev, a, img*b)
+        const float* s = O.state + pix * 3;
+        const T p = (T)O.p, q = (T)O.q;
+        if constexpr (sizeof(T) == 8) {
+            v0 = fma((T)s[0], p, v0 * q); v1 = fma((T)s[1], p, v1 * q); v2 = fma((T)s[2], p, v2 * q);
+        } else {
+            v0 = fmaf(s[0], p, v0 * q); v1 = fmaf(s[1], p, v1 * q); v2 = fmaf(s[2], p, v2 * q);
+        }
+    }
+    const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
+    if (O.state) {
+        float* s = O.state + pix * 3;
+        s[0] = f0; s[1] = f1; s[2] = f2;
+    }
+    return quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16);
+}
+
+// One finished pre-warp pixel: either park it for k_warp or commit it.
+// Every lane of the wavefront must call this (store_row_u8 shuffles); `live` masks the pixel.
+__device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, const KOut& O, int y, int x0, int lane,
+                                           bool live, float r, float g, float b,
+                                           const float* lut_g, const float* lut_inv) {
+    const int x = x0 + lane;
+    const size_t pix = (size_t)y * P.W + x;
+    uint32_t packed = 0;
+    if (promotes(P)) {
+        double v0 = 0, v1 = 0, v2 = 0;
+        if (live) tail_masks<double>(P, F, y, x, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (O.pre) {
+            if (live) { float* p = O.pre + pix * 3; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
+            return;
+        }
+        if (live) packed = commit_pixel<double>(O, pix, v0, v1, v2);
+    } else {
+        float v0 = 0, v1 = 0, v2 = 0;
+        if (live) tail_masks<float>(P, F, y, x, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (O.pre) {
+            if (live) { float* p = O.pre + pix * 3; p[0] = v0; p[1] = v1; p[2] = v2; }
+            return;
+        }
+        if (live) packed = commit_pixel<float>(O, pix, v0, v1, v2);
+    }
+    if (O.out_u8) {
+        const int valid = min(64, P.W - x0);
+        store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, valid, packed);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_point — bloom off: the chain is pointwise.  One thread per pixel, 4 rows x 64 px per block.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
+    __shared__ float lut[2 * LUT_STRIDE];
+    const bool use_lut = (P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT);
+    if (use_lut) {
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= P.H) return;                      // whole wavefront exits together
+    const int x = x0 + lane;
+    const bool live = x < P.W;
+    float r = 0, g = 0, b = 0;
+    if (live) { fetch_rgb(P, F.in, y, x, r, g, b); grade(P, r, g, b); }
+    emit_pixel(P, F, O, y, x0, lane, live, r, g, b, lut, lut + LUT_STRIDE);
+}
+
+// ---------------------------------------------------------------------------------------
+// k_phosphor — grade + separable Gaussian bloom + masks + grain.
+//
+// A block owns a 64-px-wide column strip over `seg_rows` output rows and streams down it in
+// blocks of NB rows.  Per block of rows:
+//   A  192 threads grade the (64 + 2*pad)-px-wide halo row segments into LDS (planar per channel)
+//   B  horizontal pass: a lane produces 4 adjacent pixels of one channel from 16-byte LDS reads,
+//      taps accumulated left to right with fmaf (OpenCV RowFilter order) -> ring of H-pass rows
+//   C1 vertical pass: wave c owns channel c, lane = column; each ring row is read once and fed
+//      to the NB register-resident output rows, taps top to bottom with fmaf (ColumnFilter order)
+//   C2 per-pixel: img + strength*blur, triad/scanline/vignette/flicker/grain, store
+// LDS: staging NB x 3 x (64+2pad), ring (NB+2R) x 3 x 64, blur NB x 3 x 64, LUTs 2 x 1028 floats.
+// RT >= 0 fixes the radius at compile time (loops unroll, dead taps vanish); RT < 0 = runtime R.
+// ---------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KOut O, int seg_rows) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int R = RT >= 0 ? RT : P.R;
+    const int pad = (R + 3) & ~3;
+    const int SWP = TW + 2 * pad;
+    const int ring_rows = NB + 2 * R;
+    float* stg = smem;                          // [NB][3][SWP]
+    float* ring = stg + NB * 3 * SWP;           // [ring_rows][3][TW]
+    float* blr = ring + ring_rows * 3 * TW;     // [NB][3][TW]
+    float* lut = blr + NB * 3 * TW;             // [2][LUT_STRIDE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int H = P.H, W = P.W;
+    const int x0 = blockIdx.x * TW;
+    const int y_begin = blockIdx.y * seg_rows;
+    const int y_end = min(H, y_begin + seg_rows);
+    if (y_begin >= H) return;
+
+    if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
+        for (int i = tid; i < LUT_N; i += K1_THREADS) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    }
+    const float* __restrict__ taps = P.taps;
+    const int ring_base = y_begin - R;          // ring slot of row y is (y - ring_base) % ring_rows
+
+    for (int hb = y_begin - R; hb < y_end + R; hb += NB) {
+        // ---- A: grade halo rows [hb, hb+NB) into the staging tile -------------------------
+        const int nrows = min(NB, y_end + R - hb);
+        for (int it = tid; it < nrows * SWP; it += K1_THREADS) {
+            const int j = it / SWP, i = it - j * SWP;
+            const int y = min(max(hb + j, 0), H - 1);           // BORDER_REPLICATE
+            const int x = min(max(x0 - pad + i, 0), W - 1);
+            float r, g, b;
+            fetch_rgb(P, F.in, y, x, r, g, b);
+            grade(P, r, g, b);
+            float* s = stg + (j * 3) * SWP + i;
+            s[0] = bloom_src(P, r); s[SWP] = bloom_src(P, g); s[2 * SWP] = bloom_src(P, b);
+        }
+        __syncthreads();
+        // ---- B: horizontal pass -> ring ------------------------------------------------------
+        for (int it = tid; it < nrows * 48; it += K1_THREADS) {
+            const int j = it / 48, rem = it - j * 48;
+            const int c = rem >> 4, gq = rem & 15;
+            const float4* srow = reinterpret_cast<const float4*>(stg + (j * 3 + c) * SWP) + gq;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const int nchunk = (2 * pad + 4) >> 2;
+            const int off = pad - R;
+#pragma unroll
+            for (int q = 0; q < nchunk; ++q) {      // compile-time bound when RT >= 0
+                const float4 v = srow[q];
+                const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = 4 * q + e - i - off;   // tap index: window position minus output position
+                        if (t >= 0 && t <= 2 * R) acc[i] = fmaf(ve[e], taps[t], acc[i]);
+                    }
+            }
+            const int slot = (hb + j - ring_base) % ring_rows;
+            reinterpret_cast<float4*>(ring + (slot * 3 + c) * TW)[gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        // ---- C1: vertical pass for the output rows now covered ---------------------------
+        const int out_lo = max(y_begin, hb - R);
+        const int out_hi = min(y_end, hb + NB - R);
+        const int jrows = out_hi - out_lo;
+        if (jrows > 0) {
+            {
+                const int c = tid >> 6;          // wavefront = channel
+                float acc[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[j] = 0.0f;
+                const int first = out_lo - R;    // first ring row needed
+                const int nread = jrows + 2 * R;
+                int slot = (first - ring_base) % ring_rows;
+                for (int rr = 0; rr < nread; ++rr) {
+                    const float v = ring[(slot * 3 + c) * TW + lane];
+                    slot = slot + 1 == ring_rows ? 0 : slot + 1;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int t = rr - j;
+                        if (t >= 0 && t <= 2 * R) acc[j] = fmaf(v, taps[t], acc[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) blr[(j * 3 + c) * TW + lane] = acc[j];
+            }
+            __syncthreads();
+            // ---- C2: combine + masks + store ----------------------------------------------
+            for (int it = tid; it < jrows * TW; it += K1_THREADS) {   // 192 = 3*64: a wavefront stays on one row
+                const int j = it >> 6;
+                const int y = out_lo + j;
+                const int x = x0 + lane;
+                const bool live = x < W;
+                float r = 0, g = 0, b = 0;
+                if (live) {
+                    fetch_rgb(P, F.in, y, x, r, g, b);
+                    grade(P, r, g, b);
+                    // ref:611 img = clip(img + bloom_strength * blur)
+                    r = clip01(r + P.bloom_strength * blr[(j * 3 + 0) * TW + lane]);
+                    g = clip01(g + P.bloom_strength * blr[(j * 3 + 1) * TW + lane]);
+                    b = clip01(b + P.bloom_strength * blr[(j * 3 + 2) * TW + lane]);
+                }
+                emit_pixel(P, F, O, y, x0, lane, live, r, g, b, lut, lut + LUT_STRIDE);
+            }
+        }
+        // next A overwrites stg (last read in B, two barriers ago); next B overwrites ring rows
+        // older than this block's window; next C1 overwrites blr after the two barriers above.
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_warp — barrel warp gather (ref:331-348 + cv2.remap INTER_LINEAR / BORDER_CONSTANT 0),
+// then the commit epilogue.  One thread per output pixel; taps come straight from the
+// float32 pre-warp image (L2 / Infinity-Cache resident: written by the preceding k_phosphor).
+// identity != 0: no warp, read the pre-warp pixel itself (used when only the commit is wanted).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void warp_coords(const KParams& P, int y, int x, int& ix, int& iy, int& fx, int& fy) {
+    const float xv = P.xhat[x], yv = P.yhat[y];
+    const float r2 = xv * xv + yv * yv;
+    const float factor = 1.0f + P.warp_k * r2;
+    const float mx = (xv * factor) * P.cx + P.cx;
+    const float my = (yv * factor) * P.cy + P.cy;
+    const int sx = (int)rintf(mx * 32.0f);   // cvRound: ties to even
+    const int sy = (int)rintf(my * 32.0f);
+    ix = min(max(sx >> 5, -32768), 32767);   // saturate_cast<short>
+    iy = min(max(sy >> 5, -32768), 32767);
+    fx = sx & 31; fy = sy & 31;
+}
+
+template <typename T>
+__device__ __forceinline__ void warp_sample(const KParams& P, const float* __restrict__ pre, int ix, int iy, int fx, int fy,
+                                            T& o0, T& o1, T& o2) {
+    const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
+    const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
+    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+    const bool xin0 = (unsigned)ix < (unsigned)P.W, xin1 = (unsigned)(ix + 1) < (unsigned)P.W;
+    const bool yin0 = (unsigned)iy < (unsigned)P.H, yin1 = (unsigned)(iy + 1) < (unsigned)P.H;
+    T a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    if (yin0) {
+        const float* row = pre + (size_t)iy * P.W * 3;
+        if (xin0) { const float* p = row + (size_t)ix * 3; a[0] = p[0]; a[1] = p[1]; a[2] = p[2]; }
+        if (xin1) { const float* p = row + (size_t)(ix + 1) * 3; b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; }
+    }
+    if (yin1) {
+        const float* row = pre + (size_t)(iy + 1) * P.W * 3;
+        if (xin0) { const float* p = row + (size_t)ix * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
+        if (xin1) { const float* p = row + (size_t)(ix + 1) * 3; d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; }
+    }
+    o0 = ((a[0] * (T)w00 + b[0] * (T)w01) + c[0] * (T)w10) + d[0] * (T)w11;
+    o1 = ((a[1] * (T)w00 + b[1] * (T)w01) + c[1] * (T)w10) + d[1] * (T)w11;
+    o2 = ((a[2] * (T)w00 + b[2] * (T)w01) + c[2] * (T)w10) + d[2] * (T)w11;
+}
+
+__global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict__ pre, KOut O, int identity) {
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= P.H) return;
+    const int x = x0 + lane;
+    const bool live = x < P.W;
+    const size_t pix = (size_t)y * P.W + x;
+    uint32_t packed = 0;
+    if (live) {
+        if (promotes(P)) {
+            double v0, v1, v2;
+            if (identity) { const float* p = pre + pix * 3; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
+            packed = commit_pixel<double>(O, pix, v0, v1, v2);
+        } else {
+            float v0, v1, v2;
+            if (identity) { const float* p = pre + pix * 3; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<float>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
+            packed = commit_pixel<float>(O, pix, v0, v1, v2);
+        }
+    }
+    if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), packed);
+}
+
+// crtfx_warp_map — the integer sampling map alone (parity: bit-exact against the oracle).
+__global__ void k_warp_map(KParams P, int* __restrict__ ix_out, int* __restrict__ iy_out, int* __restrict__ fxy_out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= P.W || y >= P.H) return;
+    int ix, iy, fx, fy;
+    warp_coords(P, y, x, ix, iy, fx, fy);
+    const size_t i = (size_t)y * P.W + x;
+    ix_out[i] = ix; iy_out[i] = iy; fxy_out[i] = (fy << 5) | fx;
+}
+
+// crtfx_noise_plane — the RNG's N(0,1) draw for every pixel of a frame.
+__global__ void k_noise_plane(int n, uint32_t key0, uint32_t key1, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = grain_normal(key0, key1, (uint32_t)i);
+}
+
+// crtfx_blend_quantise / crtfx_halo_correct_quantise — commit step on an existing float image.
+// mode 0: blend per O.blend.  mode 1: v = clip(local + coeff*carry) (frame-sharded halo fix-up).
+__global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __restrict__ src, const float* __restrict__ carry,
+                                                double coeff, KOut O, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int x = x0 + lane;
+    const bool live = x < W;
+    const size_t pix = (size_t)y * W + x;
+    uint32_t packed = 0;
+    if (live) {
+        const float* p = src + pix * 3;
+        if (mode == 1) {
+            const float* c = carry + pix * 3;
+            const float cf = (float)coeff;
+            const float v0 = clip01(p[0] + cf * c[0]), v1 = clip01(p[1] + cf * c[1]), v2 = clip01(p[2] + cf * c[2]);
+            packed = commit_pixel<float>(O, pix, v0, v1, v2);
+        } else {
+            packed = commit_pixel<float>(O, pix, p[0], p[1], p[2]);
+        }
+    }
+    if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * W + x0) * 3, lane, min(64, W - x0), packed);
+}
+
+}  // namespace crtfx

@@ -1,0 +1,446 @@
+"""Drop-in for the reference's per-frame API (crt_filter.py, `ref:LINE`):
+
+    make_triad_mask(h, w, strength, softness_px=0.0)      ref:220
+    make_vignette(h, w, strength)                         ref:266
+    apply_crt_effect(frame, ...) -> (out_u8, img_float)   ref:531-699
+    apply_static_effects(frame, ...) -> img_float         ref:702-861
+
+Same names, argument order, defaults and gating as the reference.  Frames may be numpy
+`uint8` H x W x 3 arrays (results come back as numpy arrays) or `torch.uint8` tensors on a ROCm
+device (results stay on that device).  The work is done by libcrtfx.so (hand-written gfx950
+kernels) through ctypes; if the library or a GPU is missing these functions raise — there is no
+CPU path here.
+
+Differences from the reference, by design:
+  * the mask builders return light descriptors (`TriadMask`, `VignetteMask`) instead of
+    H x W x 3 float32 / H x W float64 arrays (99.5 MB + 66 MB at 4K): the kernels evaluate the
+    masks from one row / two axis vectors.  `np.asarray(mask)` still yields the reference's array,
+    and plain arrays are accepted too.
+  * float results are float32 (the reference's image becomes float64 after the vignette /
+    flicker multiply; the kernels do that tail in float64 and narrow once at the store).
+  * grain comes from a counter-based RNG keyed by (noise_seed, frame_index) — cv2.randn in the
+    reference is unseeded and thread-local, so its grain is unreproducible by construction.
+    Extra keyword-only arguments `noise_seed`, `frame_index`, `noise_plane` control it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+
+# ---------------------------------------------------------------------------------------
+# mask descriptors
+# ---------------------------------------------------------------------------------------
+
+
+class TriadMask:
+    """What make_triad_mask returns: the (w, 3) row the reference repeats h times (ref:230)."""
+
+    def __init__(self, h: int, w: int, strength: float, softness_px: float, row: np.ndarray):
+        self.h, self.w, self.strength, self.softness_px = int(h), int(w), float(strength), float(softness_px)
+        self.row = row
+        self.shape = (self.h, self.w, 3)
+        self.dtype = np.dtype(np.float32)
+        self.ndim = 3
+
+    def __array__(self, dtype=None, copy=None):
+        full = np.repeat(self.row[None, :, :], self.h, axis=0)
+        return full if dtype is None else full.astype(dtype)
+
+    def key(self):
+        return ("triad_row", self.h, self.w, self.strength, self.softness_px)
+
+
+class VignetteMask:
+    """What make_vignette returns: v = 1 - strength * clip(nx^2 + ny^2, 0, 1) (ref:266-276)."""
+
+    def __init__(self, h: int, w: int, strength: float):
+        self.h, self.w, self.strength = int(h), int(w), float(strength)
+        self.shape = (self.h, self.w)
+        self.dtype = np.dtype(np.float64)
+        self.ndim = 2
+
+    def __array__(self, dtype=None, copy=None):
+        full = tables.vignette_full(self.h, self.w, self.strength)
+        return full if dtype is None else full.astype(dtype)
+
+    def key(self):
+        return ("vig_axes", self.h, self.w, self.strength)
+
+
+def make_triad_mask(h: int, w: int, strength: float, softness_px: float = 0.0) -> TriadMask:
+    """ref:220-235."""
+    return TriadMask(h, w, strength, softness_px, tables.triad_row(_lib.load(), int(w), strength, softness_px))
+
+
+def make_vignette(h: int, w: int, strength: float) -> VignetteMask:
+    """ref:266-276."""
+    return VignetteMask(h, w, strength)
+
+
+# ---------------------------------------------------------------------------------------
+# engine: one libcrtfx ctx per (device, H, W, thread)
+# ---------------------------------------------------------------------------------------
+
+_tls = threading.local()
+_seed_lock = threading.Lock()
+_seed_counter = [int.from_bytes(os.urandom(8), "little")]
+
+
+def _fresh_seed() -> int:
+    with _seed_lock:
+        _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return _seed_counter[0]
+
+
+class Engine:
+    """Owns a crtfx ctx, the host tables and the device-side per-frame scratch tensors."""
+
+    def __init__(self, device: torch.device, h: int, w: int):
+        if device.type != "cuda":
+            raise RuntimeError(f"pythoncrt_amd needs a ROCm device, got {device}")
+        self.lib = _lib.load()
+        self.device, self.h, self.w = device, int(h), int(w)
+        ctx = ctypes.c_void_p()
+        rc = self.lib.crtfx_create(device.index if device.index is not None else torch.cuda.current_device(),
+                                   self.h, self.w, _lib.PIX_U8, ctypes.byref(ctx))
+        if rc != _lib.OK:
+            raise _lib.CrtfxError(rc, f"crtfx_create({device}, {h}, {w}) failed")
+        self.ctx = ctx
+        self.params_key = None
+        self.keep = {}            # host arrays / device tensors the current params point at
+        self.auto_frame = 0
+        self.seed = _fresh_seed()
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.crtfx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- params ------------------------------------------------------------------------
+    def set_params(self, s: "Settings"):
+        key = s.key()
+        if key == self.params_key:
+            return
+        h, w = self.h, self.w
+        p = _lib.CrtfxParams()
+        p.size = ctypes.sizeof(_lib.CrtfxParams)
+        keep = {}
+        flags = 0
+        p.aberration_px = int(s.aberration_px)
+        p.grain_size = int(s.grain_size) if s.grain_size else 1
+        # colour grade gates: exact comparisons as in ref:288-302
+        if s.saturation != 1.0:
+            flags |= _lib.F_SATURATION
+        if s.temperature != 0.0:
+            flags |= _lib.F_TEMPERATURE
+            t = float(s.temperature)
+            p.r_gain = float(np.clip(1.0 + 0.5 * t, 0.5, 1.5))
+            p.b_gain = float(np.clip(1.0 - 0.5 * t, 0.5, 1.5))
+        if s.brightness != 0.0 or s.contrast != 1.0:
+            flags |= _lib.F_BRIGHTCON
+        if s.gamma != 1.0 and s.gamma > 0.0:
+            flags |= _lib.F_GAMMA
+            p.inv_gamma = 1.0 / float(s.gamma)
+        p.saturation, p.contrast, p.brightness = float(s.saturation), float(s.contrast), float(s.brightness)
+        if s.pixel_size > 1:
+            flags |= _lib.F_PIXELATE
+            keep["xmap"], keep["ymap"] = tables.pixelate_maps(h, w, s.pixel_size)
+            p.pix_xmap, p.pix_ymap = tables.ptr(keep["xmap"]), tables.ptr(keep["ymap"])
+        # bloom gate ref:599
+        if s.bloom_strength > 0.0 and (s.bloom_sigma > 0.0 or s.fast_bloom):
+            flags |= _lib.F_BLOOM
+            if s.fast_bloom:
+                flags |= _lib.F_BLOOM_FAST
+            else:
+                k = tables.bloom_ksize(s.bloom_sigma)
+                keep["taps"] = tables.gaussian_taps(k, s.bloom_sigma) if k > 1 else np.ones(1, np.float32)
+                p.bloom_radius = (k - 1) // 2
+                p.bloom_taps = tables.ptr(keep["taps"])
+            if s.bloom_threshold > 0.0:
+                flags |= _lib.F_BLOOM_THR
+                thr = float(min(0.99, max(0.0, s.bloom_threshold)))
+                p.bloom_thr, p.bloom_thr_den = thr, max(1e-6, 1.0 - thr)
+            p.bloom_strength = float(s.bloom_strength)
+        # triad ref:613
+        if s.triad_mask is not None:
+            flags |= _lib.F_TRIAD
+            tm = s.triad_mask
+            if isinstance(tm, TriadMask):
+                _check_shape(tm.shape, (h, w, 3), "triad_mask")
+                keep["triad_row"] = np.ascontiguousarray(tm.row, np.float32)
+                p.triad_row = tables.ptr(keep["triad_row"])
+            else:
+                full = _as_device_tensor(tm, self.device, torch.float32, (h, w, 3), "triad_mask")
+                keep["triad_full"] = full
+                p.triad_full_dev = full.data_ptr()
+            if tables.triad_uses_lut(s.triad_gamma, s.triad_preserve_luma):
+                flags |= _lib.F_TRIAD_LUT
+                if s.triad_preserve_luma:
+                    flags |= _lib.F_TRIAD_LUMA
+                keep["lut_g"], keep["lut_inv"] = tables.triad_luts(s.triad_gamma)
+                p.lut_g, p.lut_inv = tables.ptr(keep["lut_g"]), tables.ptr(keep["lut_inv"])
+        if s.scanline_strength > 0.0:
+            flags |= _lib.F_SCANLINES
+        if s.vignette_mask is not None:
+            flags |= _lib.F_VIGNETTE
+            vm = s.vignette_mask
+            if isinstance(vm, VignetteMask):
+                _check_shape(vm.shape, (h, w), "vignette_mask")
+                keep["nx2"], keep["ny2"] = tables.vignette_axes(h, w)
+                p.vig_nx2, p.vig_ny2 = tables.ptr(keep["nx2"]), tables.ptr(keep["ny2"])
+                p.vignette_strength = vm.strength
+            else:
+                full = _as_device_tensor(vm, self.device, torch.float64, (h, w), "vignette_mask")
+                keep["vig_full"] = full
+                p.vignette_full_dev = full.data_ptr()
+        if s.flicker_strength > 0.0 and s.flicker_hz > 0.0:
+            flags |= _lib.F_FLICKER
+        if s.noise_strength > 0.0:
+            flags |= _lib.F_NOISE
+            p.noise_scale = s.noise_strength / 255.0
+        if s.warp_strength != 0.0:
+            flags |= _lib.F_WARP
+            keep["xhat"], keep["yhat"], cx, cy = tables.warp_axes(h, w)
+            p.warp_xhat, p.warp_yhat = tables.ptr(keep["xhat"]), tables.ptr(keep["yhat"])
+            p.warp_k, p.warp_cx, p.warp_cy = float(s.warp_strength) * 0.5, cx, cy
+        p.flags = flags
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.ctx, self.lib.crtfx_set_params(self.ctx, ctypes.byref(p)))
+        self.keep = keep
+        self.flags = flags
+        self.params_key = key
+
+    # -- per-frame record ----------------------------------------------------------------
+    def frame_record(self, s: "Settings", scanline_phase_px: float, time_sec: float, noise_seed, frame_index, noise_plane, hold: list):
+        f = _lib.CrtfxFrame()
+        h, w = self.h, self.w
+        if s.scanline_strength > 0.0:
+            if s.scanline_angle == 0.0 and s.scanline_thickness == 1.0:       # ref:619
+                row = tables.scanline_rows(h, s.scanline_strength, s.scanline_period_px, [scanline_phase_px])[0]
+                t = torch.from_numpy(row).to(self.device, non_blocking=False)
+                f.scan_row_dev = t.data_ptr()
+            else:
+                plane = tables.scanline_plane(h, w, s.scanline_strength, s.scanline_period_px, scanline_phase_px,
+                                              s.scanline_angle, s.scanline_thickness)
+                t = torch.from_numpy(plane).to(self.device)
+                f.scan_plane_dev = t.data_ptr()
+            hold.append(t)
+        f.flicker_factor = tables.flicker_factor(s.flicker_strength, s.flicker_hz, time_sec) if (self.flags & _lib.F_FLICKER) else 1.0
+        if noise_plane is not None:
+            t = _as_device_tensor(noise_plane, self.device, torch.float32, None, "noise_plane")
+            hold.append(t)
+            f.noise_plane_dev = t.data_ptr()
+        f.noise_seed = (self.seed if noise_seed is None else int(noise_seed)) & 0xFFFFFFFFFFFFFFFF
+        if frame_index is None:
+            frame_index = self.auto_frame
+            self.auto_frame += 1
+        f.frame_index = int(frame_index) & 0xFFFFFFFFFFFFFFFF
+        return f
+
+
+def _check_shape(got, want, name):
+    if tuple(got) != tuple(want):
+        raise ValueError(f"{name} has shape {tuple(got)}, frame needs {tuple(want)}")
+
+
+def _as_device_tensor(a, device, dtype, shape, name) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=device, dtype=dtype).contiguous()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(device=device, dtype=dtype).contiguous()
+    if shape is not None:
+        _check_shape(t.shape, shape, name)
+    return t
+
+
+def _engine(device: torch.device, h: int, w: int) -> Engine:
+    cache = getattr(_tls, "engines", None)
+    if cache is None:
+        cache = _tls.engines = {}
+    k = (device.index, h, w)
+    e = cache.get(k)
+    if e is None:
+        e = cache[k] = Engine(device, h, w)
+    return e
+
+
+class Settings:
+    """The static keyword set shared by apply_crt_effect / apply_static_effects."""
+    FIELDS = ("scanline_strength", "triad_mask", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma",
+              "bloom_strength", "bloom_threshold", "noise_strength", "vignette_mask", "scanline_period_px", "fast_bloom",
+              "pixel_size", "brightness", "contrast", "gamma", "saturation", "temperature", "flicker_strength",
+              "flicker_hz", "grain_size", "scanline_angle", "scanline_thickness", "warp_strength")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    def key(self):
+        out = []
+        for f in self.FIELDS:
+            v = getattr(self, f)
+            if f in ("triad_mask", "vignette_mask") and v is not None:
+                v = v.key() if hasattr(v, "key") else ("array", id(v))
+            out.append(v)
+        return tuple(out)
+
+
+def _frame_to_device(frame):
+    """-> (uint8 tensor H x W x 3 on a ROCm device, was_numpy)."""
+    if isinstance(frame, torch.Tensor):
+        if frame.dtype != torch.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError(f"frame tensor must be uint8 H x W x 3, got {frame.dtype} {tuple(frame.shape)}")
+        if not frame.is_cuda:
+            raise RuntimeError("frame tensor must live on a ROCm device (pass a numpy array for host frames)")
+        return frame.contiguous(), False
+    a = np.asarray(frame)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"frame must be uint8 H x W x 3, got {a.dtype} {a.shape}")
+    if not torch.cuda.is_available():
+        raise RuntimeError("pythoncrt_amd: no ROCm device visible; there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev), True
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac):
+    if text_overlay_rgba is not None:
+        raise NotImplementedError("text_overlay_rgba is not built yet (SURVEY 8f row 1)")
+    if glitch_amp_px > 0 and glitch_height_frac > 0.0:
+        raise NotImplementedError("glitch is not built yet (SURVEY 8f row 2)")
+
+
+def apply_crt_effect(
+    frame,
+    scanline_strength: float,
+    triad_mask,
+    triad_gamma: float,
+    triad_preserve_luma: bool,
+    aberration_px: int,
+    bloom_sigma: float,
+    bloom_strength: float,
+    bloom_threshold: float,
+    noise_strength: float,
+    vignette_mask,
+    persistence: float,
+    state_prev,
+    scanline_period_px: float,
+    scanline_phase_px: float,
+    fast_bloom: bool,
+    pixel_size: int,
+    glitch_amp_px: int = 0,
+    glitch_height_frac: float = 0.0,
+    time_sec: float = 0.0,
+    brightness: float = 0.0,
+    contrast: float = 1.0,
+    gamma: float = 1.0,
+    saturation: float = 1.0,
+    temperature: float = 0.0,
+    flicker_strength: float = 0.0,
+    flicker_hz: float = 0.0,
+    grain_size: int = 1,
+    scanline_angle: float = 0.0,
+    scanline_thickness: float = 1.0,
+    warp_strength: float = 0.0,
+    text_overlay_rgba=None,
+    text_overlay_after: bool = True,
+    *,
+    noise_seed: Optional[int] = None,
+    frame_index: Optional[int] = None,
+    noise_plane=None,
+) -> Tuple[object, object]:
+    """ref:531-699 — full chain, preview-path persistence (cv2.addWeighted, ref:693) and
+    quantise.  Returns (out_u8, img_float); img_float is the next call's `state_prev`."""
+    _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac)
+    fr, was_numpy = _frame_to_device(frame)
+    h, w = fr.shape[0], fr.shape[1]
+    eng = _engine(fr.device, h, w)
+    s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
+    eng.set_params(s)
+    hold = []
+    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold)
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=fr.device)
+    blend = _lib.BLEND_NONE
+    if state_prev is not None and persistence > 0.0:                       # ref:687
+        prev = _as_device_tensor(state_prev, fr.device, torch.float32, None, "state_prev")
+        if tuple(prev.shape) != (h, w, 3):
+            raise NotImplementedError("state_prev of a different size (cv2.resize at ref:690) is not built yet")
+        state = prev.clone()      # the reference never mutates state_prev
+        blend = _lib.BLEND_PREVIEW
+    else:
+        state = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)
+    with torch.cuda.device(fr.device):
+        rc = eng.lib.crtfx_apply(eng.ctx, fr.data_ptr(), out.data_ptr(), state.data_ptr(), None, blend,
+                                 float(persistence), ctypes.byref(rec), _stream_ptr(fr.device))
+    _lib.check(eng.lib, eng.ctx, rc)
+    # `hold` (per-frame tables) may be released here: the work above is enqueued on torch's current
+    # stream and torch's caching allocator only reuses a freed block for later work on that stream.
+    if was_numpy:
+        return out.cpu().numpy(), state.cpu().numpy()
+    return out, state
+
+
+def apply_static_effects(
+    frame,
+    scanline_strength: float,
+    triad_mask,
+    triad_gamma: float,
+    triad_preserve_luma: bool,
+    aberration_px: int,
+    bloom_sigma: float,
+    bloom_strength: float,
+    bloom_threshold: float,
+    noise_strength: float,
+    vignette_mask,
+    scanline_period_px: float,
+    scanline_phase_px: float,
+    fast_bloom: bool,
+    pixel_size: int,
+    glitch_amp_px: int,
+    glitch_height_frac: float,
+    time_sec: float = 0.0,
+    brightness: float = 0.0,
+    contrast: float = 1.0,
+    gamma: float = 1.0,
+    saturation: float = 1.0,
+    temperature: float = 0.0,
+    flicker_strength: float = 0.0,
+    flicker_hz: float = 0.0,
+    grain_size: int = 1,
+    scanline_angle: float = 0.0,
+    scanline_thickness: float = 1.0,
+    warp_strength: float = 0.0,
+    text_overlay_rgba=None,
+    text_overlay_after: bool = True,
+    *,
+    noise_seed: Optional[int] = None,
+    frame_index: Optional[int] = None,
+    noise_plane=None,
+):
+    """ref:702-861 — stateless chain; returns the float image (float32 here)."""
+    _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac)
+    fr, was_numpy = _frame_to_device(frame)
+    h, w = fr.shape[0], fr.shape[1]
+    eng = _engine(fr.device, h, w)
+    s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
+    eng.set_params(s)
+    hold = []
+    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold)
+    img = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)
+    with torch.cuda.device(fr.device):
+        rc = eng.lib.crtfx_apply_static(eng.ctx, fr.data_ptr(), img.data_ptr(), ctypes.byref(rec), _stream_ptr(fr.device))
+    _lib.check(eng.lib, eng.ctx, rc)
+    return img.cpu().numpy() if was_numpy else img

@@ -1,0 +1,154 @@
+"""Host-side parameter tables for libcrtfx (product code — never imports oracle/).
+
+Everything here is O(W + H) or O(1) per frame: Gaussian taps, the single distinct row of the
+triad mask, the two 1025-entry LUTs, vignette / warp axis vectors, scanline row gains, flicker
+factor, pixelate index maps.  The per-pixel work lives in the HIP kernels.  Where the reference
+(crt_filter.py, `ref:LINE`) computes a table with numpy, the same numpy expression is used so
+the values are this machine's numpy values (np.sin / np.power are not bit-portable across CPUs).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+
+def bloom_ksize(bloom_sigma: float) -> int:
+    """ref:609 — k = max(1, round(3 sigma) * 2 + 1), python (banker's) round."""
+    return max(1, int(round(bloom_sigma * 3)) * 2 + 1)
+
+
+def triad_ksize(softness_px: float) -> int:
+    """ref:231-233."""
+    s = float(max(0.0, softness_px))
+    return max(3, int(round(s * 3)) * 2 + 1)
+
+
+def gaussian_taps(ksize: int, sigma: float) -> np.ndarray:
+    """cv::getGaussianKernel(ksize, sigma, CV_32F), sigma > 0: exp(-x^2 / 2 sigma^2) in double
+    with x counted in half-pixels, outer taps summed first then doubled plus the centre one,
+    one reciprocal to normalise, narrowed to float32."""
+    n = int(ksize)
+    if n < 1 or n % 2 == 0 or not sigma > 0.0:
+        raise ValueError(f"gaussian_taps({ksize}, {sigma})")
+    half = (n - 1) // 2
+    scale = np.float64(-0.125) / (np.float64(sigma) * np.float64(sigma))
+    xs = np.arange(1 - n, 0, 2, dtype=np.int64)                  # 1-n, 3-n, ..., -2
+    outer = np.exp((xs * xs).astype(np.float64) * scale)
+    total = np.float64(0.0)
+    for t in outer:                                              # sequential sum, as OpenCV does
+        total = total + t
+    total = total * np.float64(2.0) + np.float64(1.0)
+    inv = np.float64(1.0) / total
+    taps = np.empty(n, np.float64)
+    taps[:half] = outer * inv
+    taps[half] = inv
+    taps[half + 1:] = taps[:half][::-1]
+    return taps.astype(np.float32)
+
+
+def triad_row(lib, w: int, strength: float, softness_px: float = 0.0) -> np.ndarray:
+    """The one distinct row (w, 3) float32 of make_triad_mask (ref:220-235): the mask is a
+    row repeated h times (ref:230) and the softening blur is horizontal-only (ref:234)."""
+    x = np.arange(w)[None, :]
+    base = 1.0 - float(strength)
+    chans = [(base + float(strength) * (x % 3 == c).astype(np.float32)) for c in range(3)]
+    row = np.ascontiguousarray(np.stack(chans, axis=2).astype(np.float32)[0])      # (w, 3)
+    s = float(max(0.0, softness_px))
+    if s > 0.0:
+        taps = gaussian_taps(triad_ksize(s), s)
+        out = np.empty_like(row)
+        rc = lib.crtfx_host_blur_row(row.ctypes.data, out.ctypes.data, w, 3, taps.ctypes.data, len(taps))
+        if rc != 0:
+            raise RuntimeError(f"crtfx_host_blur_row failed: {rc}")
+        row = out
+    return row
+
+
+def triad_luts(gamma: float):
+    """ref:246-249, :260."""
+    g = float(gamma)
+    lut_x = np.linspace(0.0, 1.0, 1025, dtype=np.float32)
+    return (np.ascontiguousarray(np.power(lut_x, g, dtype=np.float32)),
+            np.ascontiguousarray(np.power(lut_x, 1.0 / g, dtype=np.float32)))
+
+
+def triad_uses_lut(gamma: float, preserve_luma: bool) -> bool:
+    """ref:240-245 — the plain-multiply shortcuts."""
+    g = float(gamma)
+    if (not preserve_luma) and abs(g - 1.0) < 1e-3:
+        return False
+    return g > 0.0
+
+
+def vignette_axes(h: int, w: int):
+    """ref:267-274 separated per axis: nx^2 (W,) and ny^2 (H,), float64.  The kernel forms
+    r2 = nx2[x] + ny2[y] and v = 1 - strength * clip(r2, 0, 1) exactly as ref:274-275."""
+    cx = (w - 1) / 2.0
+    cy = (h - 1) / 2.0
+    rx = max(1.0, w / 2.0)
+    ry = max(1.0, h / 2.0)
+    nx = (np.arange(w) - cx) / rx
+    ny = (np.arange(h) - cy) / ry
+    return np.ascontiguousarray(nx * nx), np.ascontiguousarray(ny * ny)
+
+
+def vignette_full(h: int, w: int, strength: float) -> np.ndarray:
+    """The H x W float64 array make_vignette returns (ref:266-276); only materialised when a
+    caller asks the descriptor for its array form."""
+    nx2, ny2 = vignette_axes(h, w)
+    return 1.0 - strength * np.clip(nx2[None, :] + ny2[:, None], 0.0, 1.0)
+
+
+def warp_axes(h: int, w: int):
+    """ref:336-339 — float32 normalised axes and the centre."""
+    cx = (w - 1) / 2.0
+    cy = (h - 1) / 2.0
+    x = (np.arange(w, dtype=np.float32) - cx) / max(1.0, cx)
+    y = (np.arange(h, dtype=np.float32) - cy) / max(1.0, cy)
+    return np.ascontiguousarray(x), np.ascontiguousarray(y), cx, cy
+
+
+def scanline_rows(h: int, strength: float, period_px: float, phases) -> np.ndarray:
+    """make_scanline_mask_dynamic (ref:213-217) for a batch of phases -> (B, h) float32.
+    Row b equals the reference's mask for phase_px = phases[b] bit for bit: the phase is added
+    as a float32 (a python float is a weak scalar next to the float32 `y`)."""
+    y = np.arange(h, dtype=np.float32)[None, :]
+    ph = np.asarray(phases, dtype=np.float64).astype(np.float32)[:, None]
+    s = 0.5 * (1.0 + np.sin((2.0 * np.pi / max(1e-6, period_px)) * (y + ph)))
+    return np.ascontiguousarray(1.0 - strength * s)
+
+
+def scanline_plane(h: int, w: int, strength: float, period_px: float, phase_px: float, angle_deg: float, thickness: float) -> np.ndarray:
+    """make_scanline_mask_2d (ref:308-328) — only used when angle != 0 or thickness != 1."""
+    if strength <= 0.0:
+        return np.ones((h, w), dtype=np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    theta = np.deg2rad(float(angle_deg))
+    slanted = yy + np.tan(theta) * xx
+    omega = 2.0 * np.pi / max(1e-6, float(period_px))
+    s = 0.5 * (1.0 + np.sin(omega * (slanted + float(phase_px))))
+    sharp = np.clip(float(thickness), 0.1, 4.0)
+    return np.ascontiguousarray((1.0 - float(strength) * np.power(s, 1.0 / sharp)).astype(np.float32))
+
+
+def flicker_factor(flicker_strength: float, flicker_hz: float, time_sec: float) -> float:
+    """ref:632."""
+    return float(1.0 + 0.25 * float(flicker_strength) * np.sin(2.0 * np.pi * float(flicker_hz) * float(time_sec)))
+
+
+def pixelate_maps(h: int, w: int, pixel_size: int):
+    """Composite source index of the INTER_NEAREST down/up pair (ref:580-583):
+    OpenCV's resizeNN maps dst index j to min(floor(j * (1 / (dst/src))), src-1), ratio in double."""
+    def nn(n_dst, n_src):
+        ifx = 1.0 / (n_dst / n_src)
+        return np.minimum(np.floor(np.arange(n_dst) * ifx).astype(np.int64), n_src - 1)
+
+    def one(n, p):
+        sn = max(1, n // int(p))
+        return np.ascontiguousarray(nn(sn, n)[nn(n, sn)].astype(np.int32))
+    return one(w, pixel_size), one(h, pixel_size)
+
+
+def ptr(a) -> int:
+    return 0 if a is None else a.ctypes.data

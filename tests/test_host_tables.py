@@ -1,0 +1,112 @@
+"""Host logic of the product (pythoncrt_amd/tables.py, effects.py descriptors) against the
+oracle, plus the C-ABI surface: the library loads and exports every symbol include/crtfx.h
+declares.  No GPU compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import crt_oracle as orc
+from pythoncrt_amd import _lib, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "crtfx.h")).read()
+    declared = set(re.findall(r"\b(crtfx_[a-z_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.crtfx_version() == 1
+
+
+def test_struct_layout_matches_header(lib):
+    """crtfx_set_params rejects a struct whose size field disagrees with the C sizeof."""
+    import ctypes
+    p = _lib.CrtfxParams()
+    p.size = ctypes.sizeof(_lib.CrtfxParams) - 4
+    assert lib.crtfx_set_params(None, ctypes.byref(p)) == _lib.E_INVALID
+    assert ctypes.sizeof(_lib.CrtfxParams) == 184 and ctypes.sizeof(_lib.CrtfxFrame) == 80
+
+
+def test_create_without_gpu_fails_cleanly(lib):
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = ctypes.c_void_p()
+    assert lib.crtfx_create(0, 48, 64, 0, ctypes.byref(ctx)) < 0 and not ctx.value
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import pythoncrt_amd
+    frame = np.zeros((8, 8, 3), np.uint8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pythoncrt_amd.apply_static_effects(frame, 0.6, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0)
+
+
+def test_gaussian_taps_and_ksize():
+    for s in (0.1, 0.17, 0.5, 0.83, 0.84, 1.2, 1.5, 2.5, 3.0, 3.5, 10.0):
+        assert tables.bloom_ksize(s) == orc.bloom_ksize(s)
+        k = tables.bloom_ksize(s)
+        if k > 1:
+            assert np.array_equal(tables.gaussian_taps(k, s), orc.gaussian_kernel(k, s))
+    for s in (0.2, 0.5, 0.83, 0.84, 1.0, 1.5, 2.5, 4.0):
+        assert tables.triad_ksize(s) == orc.triad_ksize(s)
+
+
+def test_triad_row_and_luts(lib):
+    for w, st, so in [(64, 0.35, 0.0), (53, 0.35, 0.5), (130, 0.8, 1.5), (7, 1.0, 4.0), (3840, 0.35, 0.5)]:
+        row = tables.triad_row(lib, w, st, so)
+        full = orc.make_triad_mask(3, w, st, so)
+        assert row.dtype == np.float32 and np.array_equal(row, full[0]) and np.array_equal(row, full[2])
+    for g in (2.2, 1.0, 0.5, 3.3):
+        a, b = tables.triad_luts(g)
+        c, d = orc.triad_luts(g)
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+    assert not tables.triad_uses_lut(1.0005, False) and tables.triad_uses_lut(1.0005, True)
+    assert not tables.triad_uses_lut(0.0, True) and tables.triad_uses_lut(2.2, False)
+
+
+def test_vignette_warp_scanline_tables():
+    for h, w, s in [(48, 64, 0.25), (7, 5, 1.0), (1, 1, 0.5), (1080, 1920, 0.6)]:
+        nx2, ny2 = tables.vignette_axes(h, w)
+        v = 1.0 - s * np.clip(nx2[None, :] + ny2[:, None], 0.0, 1.0)
+        assert np.array_equal(v, orc.make_vignette(h, w, s))
+        assert np.array_equal(tables.vignette_full(h, w, s), orc.make_vignette(h, w, s))
+    for h, w, s in [(48, 64, 0.15), (33, 47, -0.4), (1, 9, 0.15)]:
+        xh, yh, cx, cy = tables.warp_axes(h, w)
+        xv, yv = np.meshgrid(xh, yh)
+        r2 = xv * xv + yv * yv
+        factor = 1.0 + (s * 0.5) * r2
+        mx, my = orc.barrel_maps(h, w, s)
+        assert np.array_equal((xv * factor * cx + cx).astype(np.float32), mx)
+        assert np.array_equal((yv * factor * cy + cy).astype(np.float32), my)
+    phases = [0.0, 1.25, 29.0, 1234.5]
+    rows = tables.scanline_rows(720, 0.6, 2.0, phases)
+    for r, ph in zip(rows, phases):
+        assert np.array_equal(r, orc.make_scanline_mask_dynamic(720, 0.6, 2.0, ph))
+    assert np.array_equal(tables.scanline_plane(24, 40, 0.6, 2.0, 1.25, 5.0, 1.8), orc.make_scanline_mask_2d(24, 40, 0.6, 2.0, 1.25, 5.0, 1.8))
+    assert tables.flicker_factor(0.5, 7.0, 0.3) == float(1.0 + 0.25 * 0.5 * np.sin(2.0 * np.pi * 7.0 * 0.3))
+
+
+def test_pixelate_maps_match_resize_pair():
+    rng = np.random.default_rng(0)
+    for h, w, p in [(48, 64, 2), (37, 53, 3), (100, 147, 7), (1080, 1920, 2), (9, 5, 16)]:
+        img = rng.random((h, w, 3), dtype=np.float32)
+        small = orc.resize(img, (max(1, w // p), max(1, h // p)), "nearest")
+        exp = orc.resize(small, (w, h), "nearest")
+        xm, ym = tables.pixelate_maps(h, w, p)
+        assert np.array_equal(img[ym][:, xm], exp)

@@ -1,0 +1,360 @@
+"""GPU parity: pythoncrt_amd (libcrtfx.so through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Run on the MI355X box with `pytest -m gpu`.
+
+Bars:
+  * everything up to the pre-warp image — normalise, aberration, grade, bloom, triad, scanlines,
+    vignette, flicker, injected grain — is compared BIT-EXACTLY (float32(oracle) == gpu, uint8
+    equal), except the colour-grade gamma (device powf vs numpy power: <= 3e-7 absolute);
+  * the warp's integer sampling map is bit-exact; warped pixels are compared to 3e-7 absolute
+    (the reference interpolates its float64 image, the GPU the float32-stored one) and the
+    quantised frame to <= 1 LSB with < 0.1 % of samples off.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import crt_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def pc():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    import pythoncrt_amd
+    return pythoncrt_amd
+
+
+def make_frame(h, w, seed=0, kind="noise"):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    g = np.stack([(xx * 255) // max(1, w - 1), (yy * 255) // max(1, h - 1), ((xx + yy) * 255) // max(1, h + w - 2)], axis=2)
+    mix = (g + rng.integers(0, 64, (h, w, 3))) // 2 + 40
+    return np.clip(mix, 0, 255).astype(np.uint8)
+
+
+BASE = dict(scanline_strength=0.0, triad=None, triad_gamma=2.2, triad_preserve_luma=False, aberration_px=0,
+            bloom_sigma=0.0, bloom_strength=0.0, bloom_threshold=0.0, noise_strength=0.0, vignette=None,
+            scanline_period_px=2.0, scanline_phase_px=0.0, fast_bloom=False, pixel_size=1)
+
+
+def run_both(pc, frame, cfg, noise_plane=None, **kw):
+    """-> (gpu float32 image, oracle float image)."""
+    c = dict(BASE, **cfg)
+    h, w = frame.shape[:2]
+    tm_g = pc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    tm_o = orc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    vg_g = pc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    vg_o = orc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    pos = lambda tm, vg: (frame, c["scanline_strength"], tm, c["triad_gamma"], c["triad_preserve_luma"], c["aberration_px"],
+                          c["bloom_sigma"], c["bloom_strength"], c["bloom_threshold"], c["noise_strength"], vg,
+                          c["scanline_period_px"], c["scanline_phase_px"], c["fast_bloom"], c["pixel_size"], 0, 0.0)
+    got = pc.apply_static_effects(*pos(tm_g, vg_g), noise_plane=noise_plane, **kw)
+    exp = orc.apply_static_effects(*pos(tm_o, vg_o), noise_plane=noise_plane, **kw)
+    assert got.dtype == np.float32 and got.shape == frame.shape
+    return got, exp
+
+
+def assert_bit_exact(got, exp):
+    e32 = exp.astype(np.float32)
+    if not np.array_equal(got, e32):
+        d = np.abs(got.astype(np.float64) - e32)
+        raise AssertionError(f"{(got != e32).sum()} of {got.size} differ; max |d| = {d.max():.3e}")
+
+
+SIZES = [(48, 64), (37, 53), (70, 130), (9, 200)]
+
+
+def test_normalise_exhaustive(pc):
+    """a1: every uint8 value / 255.0 (true division) — all effects off."""
+    frame = np.arange(256 * 3, dtype=np.uint32).reshape(4, 64, 3) % 256
+    frame = frame.astype(np.uint8)
+    got, exp = run_both(pc, frame, {})
+    assert_bit_exact(got, exp)
+    assert set(np.unique(frame)) == set(range(256))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("d", [-8, -1, 1, 3, 8])
+def test_aberration_integer_indexing(pc, hw, d):
+    frame = make_frame(*hw, seed=d + 10)
+    got, exp = run_both(pc, frame, dict(aberration_px=d))
+    assert_bit_exact(got, exp)
+
+
+@pytest.mark.parametrize("grade", [
+    dict(brightness=0.1, contrast=1.2), dict(saturation=1.6), dict(saturation=0.0), dict(temperature=0.7),
+    dict(temperature=-1.0), dict(brightness=-0.05, contrast=0.8, saturation=1.3, temperature=-0.4)])
+def test_colour_grade_exact(pc, grade):
+    frame = make_frame(48, 64, seed=3)
+    got, exp = run_both(pc, frame, dict(aberration_px=1), **grade)
+    assert_bit_exact(got, exp)
+
+
+def test_colour_grade_gamma_tolerance(pc):
+    frame = make_frame(48, 64, seed=4)
+    got, exp = run_both(pc, frame, {}, gamma=2.2, saturation=1.2)
+    assert np.abs(got - exp.astype(np.float32)).max() <= 3e-7
+
+
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("tri", [
+    dict(triad=(0.35, 0.0)), dict(triad=(0.35, 0.5)), dict(triad=(0.35, 0.5), triad_preserve_luma=True),
+    dict(triad=(0.8, 1.5), triad_gamma=1.0), dict(triad=(0.5, 0.0), triad_gamma=1.0, triad_preserve_luma=True),
+    dict(triad=(0.35, 4.0), triad_gamma=0.5, triad_preserve_luma=True), dict(triad=(1.0, 0.2), triad_gamma=3.3)])
+def test_triad_mask(pc, hw, tri):
+    frame = make_frame(*hw, seed=5, kind="grad")
+    got, exp = run_both(pc, frame, tri)
+    assert_bit_exact(got, exp)
+
+
+def test_triad_mask_as_plain_array(pc):
+    """An arbitrary H x W x 3 array (not a descriptor) takes the full-mask path."""
+    h, w = 40, 72
+    frame = make_frame(h, w, seed=6)
+    mask = np.random.default_rng(6).random((h, w, 3), dtype=np.float32)
+    a = (frame, 0.0, mask, 2.2, True, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0)
+    assert_bit_exact(pc.apply_static_effects(*a), orc.apply_static_effects(*a))
+    assert np.array_equal(np.asarray(pc.make_triad_mask(h, w, 0.35, 0.5)), orc.make_triad_mask(h, w, 0.35, 0.5))
+
+
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("phase", [0.0, 1.25, 29.0])
+def test_scanlines_vignette_flicker(pc, hw, phase):
+    frame = make_frame(*hw, seed=7)
+    got, exp = run_both(pc, frame, dict(scanline_strength=0.6, scanline_phase_px=phase, vignette=0.25, aberration_px=1,
+                                        triad=(0.35, 0.5)),
+                        time_sec=0.3, flicker_strength=0.5, flicker_hz=7.0)
+    assert exp.dtype == np.float64
+    assert_bit_exact(got, exp)
+    got, exp = run_both(pc, frame, dict(scanline_strength=0.6, scanline_phase_px=phase))   # config-1 shape
+    assert exp.dtype == np.float32
+    assert_bit_exact(got, exp)
+
+
+def test_scanlines_2d_and_vignette_array(pc):
+    h, w = 50, 90
+    frame = make_frame(h, w, seed=8)
+    got, exp = run_both(pc, frame, dict(scanline_strength=0.7, scanline_phase_px=3.0), scanline_angle=7.5, scanline_thickness=1.8)
+    assert_bit_exact(got, exp)
+    vig = orc.make_vignette(h, w, 0.6)
+    a = (frame, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, vig, 2.0, 0.0, False, 1, 0, 0.0)
+    assert_bit_exact(pc.apply_static_effects(*a), orc.apply_static_effects(*a))
+    assert np.array_equal(np.asarray(pc.make_vignette(h, w, 0.6)), vig)
+
+
+@pytest.mark.parametrize("hw", SIZES + [(150, 64)])
+@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 6.5])
+def test_bloom_bit_exact(pc, hw, sigma):
+    """a5: separable Gaussian (LDS strips, ring H-pass, register-blocked V-pass) — same fmaf
+    accumulation order as the oracle, so equal to the last bit, borders included."""
+    frame = make_frame(*hw, seed=9)
+    got, exp = run_both(pc, frame, dict(bloom_sigma=sigma, bloom_strength=0.25, aberration_px=1))
+    assert_bit_exact(got, exp)
+
+
+def test_bloom_threshold_and_strength(pc):
+    frame = make_frame(64, 96, seed=10, kind="grad")
+    got, exp = run_both(pc, frame, dict(bloom_sigma=3.0, bloom_strength=1.5, bloom_threshold=0.4), brightness=0.05, contrast=1.1)
+    assert_bit_exact(got, exp)
+    imp = np.zeros((41, 70, 3), np.uint8)
+    imp[20, 35] = 255
+    got, exp = run_both(pc, imp, dict(bloom_sigma=3.0, bloom_strength=1.0))
+    assert_bit_exact(got, exp)
+    assert got[20, 35, 0] == 1.0 and 0 < got[11, 26, 0] < 1e-4 and got[10, 35, 0] == 0.0   # 19x19 support
+
+
+def test_grain_injected_plane_and_rng(pc):
+    h, w = 64, 128
+    frame = make_frame(h, w, seed=11, kind="grad")
+    plane = np.random.default_rng(11).standard_normal((h, w), dtype=np.float32)
+    cfg = dict(noise_strength=8.0, vignette=0.25, scanline_strength=0.6, scanline_phase_px=1.0)
+    got, exp = run_both(pc, frame, cfg, noise_plane=plane)
+    assert_bit_exact(got, exp)
+    got32, exp32 = run_both(pc, frame, dict(noise_strength=8.0), noise_plane=plane)     # float32 tail
+    assert exp32.dtype == np.float32
+    assert_bit_exact(got32, exp32)
+    # in-kernel RNG == the plane crtfx_noise_plane exports for the same (seed, frame)
+    from pythoncrt_amd import effects
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = effects._engine(dev, h, w)
+    out = torch.empty((h, w), dtype=torch.float32, device=dev)
+    rc = eng.lib.crtfx_noise_plane(eng.ctx, 1234, 7, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    gpu_plane = out.cpu().numpy()
+    c = dict(BASE, **cfg)
+    a = (frame, c["scanline_strength"], None, 2.2, False, 0, 0.0, 0.0, 0.0, c["noise_strength"], pc.make_vignette(h, w, 0.25),
+         2.0, 1.0, False, 1, 0, 0.0)
+    rng_img = pc.apply_static_effects(*a, noise_seed=1234, frame_index=7)
+    plane_img = pc.apply_static_effects(*a, noise_plane=gpu_plane)
+    assert np.array_equal(rng_img, plane_img)
+    other = pc.apply_static_effects(*a, noise_seed=1234, frame_index=8)
+    assert not np.array_equal(rng_img, other)
+
+
+def test_grain_rng_statistics(pc):
+    from pythoncrt_amd import effects
+    h, w = 1080, 1920
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = effects._engine(dev, h, w)
+    out = torch.empty((h, w), dtype=torch.float32, device=dev)
+    eng.lib.crtfx_noise_plane(eng.ctx, 99, 0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    z = out.cpu().numpy().astype(np.float64)
+    n = z.size
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.var() - 1.0) < 5 * np.sqrt(2.0 / n)
+    assert abs((z ** 3).mean()) < 0.02 and abs((z ** 4).mean() - 3.0) < 0.05
+    assert abs((z[:, 1:] * z[:, :-1]).mean()) < 5 / np.sqrt(n) and abs((z[1:] * z[:-1]).mean()) < 5 / np.sqrt(n)
+    from scipy import stats
+    assert stats.kstest(z.ravel()[::97], "norm").statistic < 0.01
+    out2 = torch.empty_like(out)
+    eng.lib.crtfx_noise_plane(eng.ctx, 99, 1, out2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert abs((z * out2.cpu().numpy()).mean()) < 5 / np.sqrt(n)     # frames are independent
+
+
+@pytest.mark.parametrize("hw,s", [((48, 64), 0.15), ((33, 47), -0.4), ((96, 128), 1.0), ((70, 130), 0.15)])
+def test_warp_map_bit_exact(pc, hw, s):
+    """Integer tap origins and 5-bit fractions of the barrel map: equal to the oracle's."""
+    from pythoncrt_amd import effects
+    h, w = hw
+    frame = make_frame(h, w, seed=12)
+    pc.apply_static_effects(frame, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0, warp_strength=s)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = effects._engine(dev, h, w)
+    ix, iy, fxy = (torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(3))
+    rc = eng.lib.crtfx_warp_map(eng.ctx, ix.data_ptr(), iy.data_ptr(), fxy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    mx, my = orc.barrel_maps(h, w, s)
+    oix, oiy, ofxy = orc.remap_quantise(mx, my)
+    assert np.array_equal(ix.cpu().numpy(), oix) and np.array_equal(iy.cpu().numpy(), oiy) and np.array_equal(fxy.cpu().numpy(), ofxy)
+
+
+FULL = dict(scanline_strength=0.6, triad=(0.35, 0.5), aberration_px=1, bloom_sigma=1.2, bloom_strength=0.25,
+            noise_strength=1.5, vignette=0.25, scanline_phase_px=1.25)
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (70, 130), (135, 240)])
+@pytest.mark.parametrize("sigma", [1.2, 3.0])
+def test_full_chain_with_warp(pc, hw, sigma):
+    """BASELINE config 2 / 3 parameter sets at oracle-friendly sizes."""
+    h, w = hw
+    frame = make_frame(h, w, seed=13, kind="grad")
+    plane = np.random.default_rng(13).standard_normal((h, w), dtype=np.float32)
+    got, exp = run_both(pc, frame, dict(FULL, bloom_sigma=sigma), noise_plane=plane, warp_strength=0.15)
+    assert np.abs(got.astype(np.float64) - exp).max() <= 3e-7
+    # without the warp the same chain is bit-exact
+    got, exp = run_both(pc, frame, dict(FULL, bloom_sigma=sigma), noise_plane=plane)
+    assert_bit_exact(got, exp)
+
+
+def crt_args(frame, tm, vg, persistence, state, phase, c):
+    return (frame, c["scanline_strength"], tm, c["triad_gamma"], c["triad_preserve_luma"], c["aberration_px"], c["bloom_sigma"],
+            c["bloom_strength"], c["bloom_threshold"], c["noise_strength"], vg, persistence, state, c["scanline_period_px"], phase,
+            c["fast_bloom"], c["pixel_size"])
+
+
+@pytest.mark.parametrize("warp", [0.0, 0.15])
+def test_apply_crt_effect_sequence(pc, warp):
+    """Stateful preview path: 4 frames threaded through state_prev (cv2.addWeighted blend)."""
+    h, w = 70, 130
+    c = dict(BASE, **FULL)
+    tm_g, tm_o = pc.make_triad_mask(h, w, 0.35, 0.5), orc.make_triad_mask(h, w, 0.35, 0.5)
+    vg_g, vg_o = pc.make_vignette(h, w, 0.25), orc.make_vignette(h, w, 0.25)
+    sg = so = None
+    for i in range(4):
+        frame = make_frame(h, w, seed=20 + i, kind="grad")
+        plane = np.random.default_rng(30 + i).standard_normal((h, w), dtype=np.float32)
+        ug, sg = pc.apply_crt_effect(*crt_args(frame, tm_g, vg_g, 0.5, sg, float(i), c), warp_strength=warp, noise_plane=plane)
+        uo, so = orc.apply_crt_effect(*crt_args(frame, tm_o, vg_o, 0.5, so, float(i), c), warp_strength=warp, noise_plane=plane)
+        assert ug.dtype == np.uint8 and sg.dtype == np.float32
+        assert np.abs(sg.astype(np.float64) - so).max() <= 4e-7
+        d = np.abs(ug.astype(np.int16) - uo.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+        if warp == 0.0 and i == 0:
+            assert np.array_equal(ug, uo) and np.array_equal(sg, so.astype(np.float32))
+
+
+def test_tensor_in_tensor_out_and_purity(pc):
+    h, w = 48, 64
+    frame = make_frame(h, w, seed=40)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(frame).to(dev)
+    tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    c = dict(BASE, **FULL)
+    u, s = pc.apply_crt_effect(*crt_args(t, tm, vg, 0.2, None, 0.0, c), noise_seed=1, frame_index=0)
+    assert isinstance(u, torch.Tensor) and u.device == t.device and u.dtype == torch.uint8 and s.dtype == torch.float32
+    assert np.array_equal(t.cpu().numpy(), frame)                 # callee never mutates the frame (ref:569 copies)
+    s_before = s.clone()
+    u2, s2 = pc.apply_crt_effect(*crt_args(t, tm, vg, 0.2, s, 1.0, c), noise_seed=1, frame_index=1)
+    assert torch.equal(s, s_before) and not torch.equal(s2, s)   # state_prev is not mutated either
+    un, sn = pc.apply_crt_effect(*crt_args(frame, tm, vg, 0.2, None, 0.0, c), noise_seed=1, frame_index=0)
+    assert isinstance(un, np.ndarray) and np.array_equal(un, u.cpu().numpy()) and np.array_equal(sn, s.cpu().numpy())
+
+
+def test_errors_are_loud(pc):
+    frame = make_frame(48, 64)
+    a = [frame, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, True, 1, 0, 0.0]   # fast_bloom=True
+    with pytest.raises(Exception, match="fast"):
+        pc.apply_static_effects(*a)
+    with pytest.raises(ValueError):
+        pc.apply_static_effects(frame[:, :, :2], *a[1:])
+    with pytest.raises(ValueError):
+        pc.apply_static_effects(frame, 0.0, pc.make_triad_mask(10, 10, 0.3), *a[3:])
+    with pytest.raises(NotImplementedError):
+        pc.apply_static_effects(*a[:13], False, 1, 5, 0.5)
+
+
+# ---- BASELINE full sizes: size-independent properties ------------------------------------------
+
+@pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
+def test_full_size_properties(pc, hw):
+    h, w = hw
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    frame = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, generator=g)
+    fd = frame.to(dev)
+    off = (fd, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 0.0, None, 2.0, 0.0, False, 1)
+    u, s = pc.apply_crt_effect(*off)
+    assert torch.equal(u, fd)                                   # identity chain: u8 -> /255 -> *255 round trip
+    assert torch.equal(s, fd.float() / 255.0)
+    # aberration only: an exact wrap-around shift of R and B (integer indexing)
+    a = list(off)
+    a[5] = 3
+    u, _ = pc.apply_crt_effect(*a)
+    exp = torch.stack([torch.roll(fd[:, :, 0], 3, 1), fd[:, :, 1], torch.roll(fd[:, :, 2], -3, 1)], dim=2)
+    assert torch.equal(u, exp)
+    # bloom of a constant image is that constant (taps sum to 1 within float rounding); borders replicate
+    const = torch.full((h, w, 3), 100, dtype=torch.uint8, device=dev)
+    b = list(off)
+    b[0], b[6], b[7] = const, 3.0, 0.5
+    img = pc.apply_static_effects(*b[:11], *b[13:], 0, 0.0)
+    v = 100 / 255
+    assert float((img - (v + 0.5 * v)).abs().max()) < 2e-6
+    # full chain, config-3 parameters: deterministic for a fixed (seed, frame); finite; in range;
+    # and equal to the oracle on a window cut from the middle of the frame
+    tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    c = dict(BASE, **dict(FULL, bloom_sigma=3.0))
+    u1, s1 = pc.apply_crt_effect(*crt_args(fd, tm, vg, 0.0, None, 1.25, c), warp_strength=0.15, noise_seed=5, frame_index=2)
+    u2, s2 = pc.apply_crt_effect(*crt_args(fd, tm, vg, 0.0, None, 1.25, c), warp_strength=0.15, noise_seed=5, frame_index=2)
+    assert torch.equal(u1, u2) and torch.equal(s1, s2)
+    assert bool(torch.isfinite(s1).all()) and float(s1.min()) >= 0.0 and float(s1.max()) <= 1.0
+    assert not bool(u1[0, 0].any()) and not bool(u1[-1, -1].any())   # barrel warp: corners sample outside -> 0
+
+
+def test_1080p_frame_against_oracle(pc):
+    """One whole 1080p frame, BASELINE config 2 parameters, against the oracle (a few seconds of CPU)."""
+    h, w = 1080, 1920
+    frame = make_frame(h, w, seed=50, kind="grad")
+    plane = np.random.default_rng(50).standard_normal((h, w), dtype=np.float32)
+    got, exp = run_both(pc, frame, FULL, noise_plane=plane)
+    assert_bit_exact(got, exp)
+    gotw, expw = run_both(pc, frame, FULL, noise_plane=plane, warp_strength=0.15)
+    assert np.abs(gotw.astype(np.float64) - expw).max() <= 3e-7
+    d = np.abs(orc.convert_scale_abs(gotw).astype(np.int16) - orc.convert_scale_abs(expw).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
