@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the per-frame CRT effect chain on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4}] [--batch B]
+
+One "step" = one pass of the hot path (k_phosphor -> k_warp per frame, enqueued back to back by
+crtfx_process_batch) over one batch of B synthetic frames already resident in HBM.  The default
+workload is BASELINE.json configs[2] — the 4K full chain (Gaussian bloom sigma=3, warp 0.15), the
+configuration the metric is quoted on.  N > 1: one process per GPU (torch.distributed.run), the
+frame batches are sharded with no data-path collective for persistence 0 (weak scaling: every
+rank processes its own B frames per step); --config 4 adds the one-frame persistence carry over
+RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def synth_frames(b, h, w, device, seed=1234):
+    """50 % smooth moving gradient + 50 % uniform noise, seed 1234+i, generated on device."""
+    out = torch.empty((b, h, w, 3), dtype=torch.uint8, device=device)
+    yy = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    for i in range(b):
+        g = torch.Generator(device=device).manual_seed(seed + i)
+        noise = torch.randint(0, 256, (h, w, 3), device=device, dtype=torch.int32, generator=g)
+        grad = torch.stack([((xx + 7 * i) % w) * (255.0 / w) + 0 * yy, ((yy + 5 * i) % h) * (255.0 / h) + 0 * xx,
+                            ((xx + yy + 3 * i) % (h + w)) * (255.0 / (h + w))], dim=2).to(torch.int32)
+        out[i] = ((noise + grad) // 2).clamp_(0, 255).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(rs, h, w, fps, n_frames, seed=1234):
+    """The oracle (CPU restatement of the reference chain: numpy + C for the OpenCV ops) on a
+    bounded sample of the same workload, single thread.  A reported baseline, not the target."""
+    from oracle import crt_oracle as orc
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames = []
+    for i in range(n_frames):
+        noise = rng.integers(0, 256, (h, w, 3), dtype=np.int32)
+        grad = np.stack([((xx + 7 * i) % w) * (255.0 / w), ((yy + 5 * i) % h) * (255.0 / h), ((xx + yy + 3 * i) % (h + w)) * (255.0 / (h + w))], axis=2).astype(np.int32)
+        frames.append(np.clip((noise + grad) // 2, 0, 255).astype(np.uint8))
+    planes = [rng.standard_normal((h, w), dtype=np.float32) for _ in range(n_frames)] if rs.noise_strength > 0 else None
+    params = dict(scanline_strength=rs.scanline_strength, triad_gamma=rs.triad_gamma, triad_preserve_luma=rs.triad_preserve_luma,
+                  aberration_px=rs.aberration_px, bloom_sigma=rs.bloom_sigma, bloom_strength=rs.bloom_strength,
+                  bloom_threshold=rs.bloom_threshold, noise_strength=rs.noise_strength, scanline_period_px=rs.scanline_period_px,
+                  fast_bloom=rs.fast_bloom, pixel_size=rs.pixel_size, warp_strength=rs.warp_strength)
+    orc._lib()
+    t0 = time.perf_counter()
+    orc.process_frames(frames, params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                       rs.vignette_strength, noise_planes=planes)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4])
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 16 at 4K, 32 at 1080p)")
+    ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from pythoncrt_amd.pipeline import FramePipeline, FrameShard, baseline_config, halo_exchange_correct
+    rs, h, w = baseline_config(a.config)
+    fps = 30.0
+    B = a.batch or (16 if h >= 2160 else 32)
+    pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234)
+    frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank)
+    out = torch.empty_like(frames)
+    p = rs.persistence
+    shard = FrameShard(world, rank, B)
+    local_states = torch.empty((B, h, w, 3), dtype=torch.float32, device=device) if (p > 0 and world > 1) else None
+    zero_state = torch.zeros((h, w, 3), dtype=torch.float32, device=device) if local_states is not None else None
+
+    # frame indices: step s, rank r owns global frames [(s*world + r)*B, ... + B)
+    def records(step):
+        return pipe.frame_records((step * world + rank) * B, B)
+
+    recs = [records(s) for s in range(a.warmup + a.steps)]     # host-side tables built outside the timed region
+    carry = None
+    state = None
+
+    def one_step(s):
+        nonlocal carry, state
+        if local_states is not None:
+            st = zero_state.clone()
+            pipe.run(frames, state=st, out=out, records=recs[s], local_states=local_states)
+            carry = halo_exchange_correct(pipe, shard, local_states, out, s * world + rank, carry)
+            if world > 1:       # last rank's true final state seeds rank 0's next round
+                t = carry if rank == world - 1 else torch.empty_like(zero_state)
+                dist.broadcast(t, src=world - 1)
+                carry = t
+        else:
+            _, state = pipe.run(frames, state=state, out=out, records=recs[s])
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for s in range(a.warmup):
+        one_step(s)
+    sync()
+    prof = not a.no_profile
+    pipe.profile(prof)
+    t0 = time.perf_counter()
+    for s in range(a.warmup, a.warmup + a.steps):
+        one_step(s)
+    sync()
+    dt = time.perf_counter() - t0
+    kt = pipe.profile_read() if prof else {}
+    pipe.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_frames = B * a.steps * world
+    fps_out = total_frames / dt
+    px = h * w
+    alg_bytes_frame = px * (6 + (24 if p > 0 else 0))       # u8 in + u8 out (+ f32 state r/w)
+    res = {
+        "metric": "4K frames/sec (whole node) + achieved HBM GB/s as % of MI355X peak" if a.config == 3 else f"{h}p frames/sec (whole node)",
+        "value": round(fps_out, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{a.config - 1}]: {w}x{h} full chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
+                               f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, u8 in/out",
+                   "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
+    }
+    if rank == 0:
+        if kt:
+            ms_frame = sum(v[0] for v in kt.values() if v[1])
+            dom = max(kt.items(), key=lambda kv: kv[1][0])
+            achieved = alg_bytes_frame / (ms_frame * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(f"config{a.config}")
+                except Exception:
+                    traffic = None
+            res["roofline"] = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "per-frame chain k_phosphor -> k_warp (algorithmic bytes of the whole frame / summed kernel time)",
+                "algorithmic_bytes_per_frame": alg_bytes_frame, "dominant_kernel": dom[0],
+                "kernels_ms": {k: round(v[0], 4) for k, v in kt.items()}, "launches": {k: v[1] for k, v in kt.items()},
+            }
+        if world == 1 and a.cpu_frames != 0:
+            n_cpu = a.cpu_frames if a.cpu_frames > 0 else (3 if h >= 2160 else 10)
+            v, secs = cpu_baseline(rs, h, w, fps, n_cpu)
+            res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n_cpu} frames of the same {w}x{h} workload through oracle/ (numpy + C restatement of the OpenCV ops), "
+                                             f"{secs:.1f} s on 1 of {os.cpu_count()} host cores"}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

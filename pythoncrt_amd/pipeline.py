@@ -1,0 +1,244 @@
+"""The hot slice of process_video (crt_filter.py ref:919-920, :1037-1131) over device-resident
+frames: masks built once per render, phase = i/fps*speed (ref:1043), time_sec = i/fps (ref:1064),
+frame-parallel static effects, in-order persistence IIR (ref:1086-1096) and uint8 quantise
+(ref:1098).  The reference parallelises frames over <= 2 worker threads (ref:1015-1017); here a
+run of frames is enqueued back to back on one GPU, and runs are sharded across GPUs by
+`FrameShard` (one process per GPU; RCCL only for the one-frame persistence carry).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from .effects import Engine, Settings, make_triad_mask, make_vignette
+
+
+@dataclass
+class RenderSettings:
+    """process_video's effect keywords (ref:864-911) with the CLI defaults (ref:1155-1206)."""
+    scanline_strength: float = 0.6
+    triad_strength: float = 0.35
+    triad_gamma: float = 2.2
+    triad_preserve_luma: bool = False
+    triad_softness: float = 0.5
+    aberration_px: int = 1
+    bloom_sigma: float = 1.2
+    bloom_strength: float = 0.25
+    bloom_threshold: float = 0.0
+    noise_strength: float = 1.5
+    vignette_strength: float = 0.25
+    persistence: float = 0.2
+    scanline_speed_px_s: float = 30.0
+    scanline_period_px: float = 2.0
+    fast_bloom: bool = True
+    pixel_size: int = 2
+    brightness: float = 0.0
+    contrast: float = 1.0
+    gamma: float = 1.0
+    saturation: float = 1.0
+    temperature: float = 0.0
+    flicker_strength: float = 0.0
+    flicker_hz: float = 0.0
+    grain_size: int = 1
+    scanline_angle: float = 0.0
+    scanline_thickness: float = 1.0
+    warp_strength: float = 0.0
+    glitch_amp_px: int = 0
+    glitch_height_frac: float = 0.0
+
+    def static_settings(self, h: int, w: int) -> Settings:
+        """ref:919-920 — masks are built once per render, None when the strength is 0."""
+        tm = make_triad_mask(h, w, self.triad_strength, self.triad_softness) if self.triad_strength > 0.0 else None
+        vg = make_vignette(h, w, self.vignette_strength) if self.vignette_strength > 0.0 else None
+        return Settings(
+            scanline_strength=self.scanline_strength, triad_mask=tm, triad_gamma=float(self.triad_gamma),
+            triad_preserve_luma=bool(self.triad_preserve_luma), aberration_px=self.aberration_px,
+            bloom_sigma=self.bloom_sigma, bloom_strength=self.bloom_strength, bloom_threshold=float(self.bloom_threshold),
+            noise_strength=self.noise_strength, vignette_mask=vg, scanline_period_px=self.scanline_period_px,
+            fast_bloom=self.fast_bloom, pixel_size=self.pixel_size, brightness=float(self.brightness),
+            contrast=float(self.contrast), gamma=float(self.gamma), saturation=float(self.saturation),
+            temperature=float(self.temperature), flicker_strength=float(self.flicker_strength),
+            flicker_hz=float(self.flicker_hz), grain_size=int(self.grain_size), scanline_angle=float(self.scanline_angle),
+            scanline_thickness=float(self.scanline_thickness), warp_strength=float(self.warp_strength))
+
+
+# BASELINE.json configs as RenderSettings
+def baseline_config(n: int) -> Tuple[RenderSettings, int, int]:
+    off = dict(triad_strength=0.0, aberration_px=0, bloom_strength=0.0, noise_strength=0.0, vignette_strength=0.0,
+               persistence=0.0, fast_bloom=False, pixel_size=1)
+    full = dict(scanline_strength=0.6, triad_strength=0.35, triad_gamma=2.2, triad_softness=0.5, triad_preserve_luma=False,
+                aberration_px=1, bloom_strength=0.25, fast_bloom=False, warp_strength=0.15, vignette_strength=0.25,
+                noise_strength=1.5, grain_size=1, pixel_size=1, persistence=0.0)
+    if n == 1:
+        return RenderSettings(**dict(off, scanline_strength=0.6, scanline_period_px=2.0, scanline_speed_px_s=30.0)), 720, 1280
+    if n == 2:
+        return RenderSettings(**dict(full, bloom_sigma=1.2)), 1080, 1920
+    if n == 3:
+        return RenderSettings(**dict(full, bloom_sigma=3.0)), 2160, 3840
+    if n == 4:
+        return RenderSettings(**dict(full, bloom_sigma=1.2, persistence=0.5)), 1080, 1920
+    raise ValueError(f"BASELINE config {n} is not runnable on this build (config 5 needs fp16 pixels)")
+
+
+class FramePipeline:
+    """One GPU's worth of the render loop."""
+
+    def __init__(self, device: torch.device, h: int, w: int, settings: RenderSettings, fps: float = 30.0,
+                 noise_seed: int = 0):
+        self.device, self.h, self.w, self.rs, self.fps = device, int(h), int(w), settings, float(fps)
+        self.noise_seed = int(noise_seed)
+        if settings.glitch_amp_px > 0 and settings.glitch_height_frac > 0.0:
+            raise NotImplementedError("glitch is not built yet (SURVEY 8f row 2)")
+        self.engine = Engine(device, h, w)
+        self.static = settings.static_settings(self.h, self.w)
+        self.engine.set_params(self.static)
+        self.lib = self.engine.lib
+
+    # ---- per-frame records for frames [first, first+n) -------------------------------------
+    def frame_records(self, first: int, n: int, noise_planes: Optional[torch.Tensor] = None):
+        rs, st = self.rs, self.static
+        idx = np.arange(first, first + n)
+        recs = (_lib.CrtfxFrame * n)()
+        hold = []
+        if st.scanline_strength > 0.0:
+            phases = [(int(i) / float(self.fps)) * rs.scanline_speed_px_s for i in idx]             # ref:1043
+            if st.scanline_angle == 0.0 and st.scanline_thickness == 1.0:
+                rows = torch.from_numpy(tables.scanline_rows(self.h, st.scanline_strength, st.scanline_period_px, phases)).to(self.device)
+                hold.append(rows)
+                for j in range(n):
+                    recs[j].scan_row_dev = rows[j].data_ptr()
+            else:
+                planes = torch.from_numpy(np.stack([tables.scanline_plane(self.h, self.w, st.scanline_strength, st.scanline_period_px,
+                                                                          ph, st.scanline_angle, st.scanline_thickness) for ph in phases])).to(self.device)
+                hold.append(planes)
+                for j in range(n):
+                    recs[j].scan_plane_dev = planes[j].data_ptr()
+        flick = (self.engine.flags & _lib.F_FLICKER) != 0
+        for j, i in enumerate(idx):
+            recs[j].flicker_factor = tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) if flick else 1.0  # ref:1064
+            recs[j].noise_seed = self.noise_seed & 0xFFFFFFFFFFFFFFFF
+            recs[j].frame_index = int(i)
+            if noise_planes is not None:
+                recs[j].noise_plane_dev = noise_planes[j].data_ptr()
+        if noise_planes is not None:
+            hold.append(noise_planes)
+        return recs, hold
+
+    def run(self, frames: torch.Tensor, first_index: int = 0, state: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None, noise_planes: Optional[torch.Tensor] = None,
+            records=None, local_states: Optional[torch.Tensor] = None, force_blend_first: bool = False):
+        """frames: uint8 (N, H, W, 3) on self.device.  Returns (out uint8 (N, H, W, 3), state).
+        `state` is the persistence carry (float32 H x W x 3) from the previous run, or None at the
+        start of the clip (the first frame then passes through unblended, ref:1094-1095)."""
+        n = frames.shape[0]
+        assert frames.dtype == torch.uint8 and tuple(frames.shape[1:]) == (self.h, self.w, 3) and frames.is_contiguous()
+        if out is None:
+            out = torch.empty_like(frames)
+        p = float(self.rs.persistence)
+        recs, hold = records if records is not None else self.frame_records(first_index, n, noise_planes)
+        has_state = state is not None
+        if p > 0.0 and state is None:
+            state = torch.empty((self.h, self.w, 3), dtype=torch.float32, device=self.device)
+        stride = self.h * self.w * 3
+        with torch.cuda.device(self.device):
+            rc = self.lib.crtfx_process_batch(
+                self.engine.ctx, frames.data_ptr(), stride, out.data_ptr(), stride, n, recs,
+                state.data_ptr() if (p > 0.0) else None, p, 1 if (has_state or force_blend_first) else 0,
+                local_states.data_ptr() if local_states is not None else None,
+                torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self.lib, self.engine.ctx, rc)
+        self._hold = hold      # keep per-frame tables alive until the next run replaces them
+        return out, (state if p > 0.0 else None)
+
+    # ---- profiling hooks (HIP events recorded by the library on the launch stream) ----------
+    def profile(self, on: bool):
+        _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_profile_enable(self.engine.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        out = {}
+        for k, name in ((0, "k_phosphor"), (1, "k_warp")):
+            ms, cnt = ctypes.c_double(), ctypes.c_int()
+            _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_profile_read(self.engine.ctx, k, ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# frame sharding across ranks
+# ---------------------------------------------------------------------------------------
+
+@dataclass
+class FrameShard:
+    """Contiguous chunks of `chunk` frames dealt round-robin: frame t -> rank (t // chunk) % world.
+    With persistence p > 0 each rank scans its chunk from a ZERO incoming state (local_t), and
+    the true state is local_t + p^(t - t0 + 1) * carry_in, carry_in being the previous chunk's
+    final state (ref:1092 is linear in the state; its clip is inactive for inputs in [0,1])."""
+    world: int
+    rank: int
+    chunk: int
+
+    def owner(self, t: int) -> int:
+        return (t // self.chunk) % self.world
+
+    def my_chunks(self, n_frames: int) -> List[Tuple[int, int]]:
+        out = []
+        c = 0
+        while c * self.chunk < n_frames:
+            if c % self.world == self.rank:
+                out.append((c * self.chunk, min(n_frames, (c + 1) * self.chunk)))
+            c += 1
+        return out
+
+    @staticmethod
+    def settle_frames(p: float, eps: float = 2.0 ** -24) -> int:
+        """Frames after which a unit error in the incoming state has decayed below eps."""
+        if p <= 0.0:
+            return 0
+        return int(math.ceil(math.log(eps) / math.log(p)))
+
+
+def halo_exchange_correct(pipe: FramePipeline, shard: FrameShard, local_states: torch.Tensor, out: torch.Tensor,
+                          chunk_index: int, carry_prev_round: Optional[torch.Tensor], group=None):
+    """One chunk's halo step: send my chunk-final local state to the ring successor, receive the
+    predecessor's, and re-quantise my frames with the p^j-weighted carry added.
+
+    local_states: (n, H, W, 3) float32 local scan of this chunk (zero incoming state).
+    carry_prev_round: for rank 0, the true final state of the last chunk of the previous round
+    (None for the very first chunk of the clip).
+    Returns this chunk's true final state (what the successor needs... plus what rank world-1
+    hands to rank 0 for the next round)."""
+    import torch.distributed as dist
+    p = float(pipe.rs.persistence)
+    n = local_states.shape[0]
+    w = shard.world
+    final_local = local_states[n - 1]
+    if w > 1:
+        recv = torch.empty_like(final_local)
+        ops = []
+        if shard.rank < w - 1:
+            ops.append(dist.P2POp(dist.isend, final_local.contiguous(), shard.rank + 1, group))
+        if shard.rank > 0:
+            ops.append(dist.P2POp(dist.irecv, recv, shard.rank - 1, group))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        carry = recv if shard.rank > 0 else carry_prev_round
+    else:
+        carry = carry_prev_round
+    if carry is None:
+        return final_local
+    stream = torch.cuda.current_stream(pipe.device).cuda_stream
+    true_final = torch.empty_like(final_local)
+    with torch.cuda.device(pipe.device):
+        for j in range(n):
+            coeff = p ** (j + 1)
+            rc = pipe.lib.crtfx_halo_correct_quantise(pipe.engine.ctx, local_states[j].data_ptr(), carry.data_ptr(), coeff,
+                                                      true_final.data_ptr() if j == n - 1 else None, out[j].data_ptr(), stream)
+            _lib.check(pipe.lib, pipe.engine.ctx, rc)
+    return true_final

@@ -322,7 +322,7 @@ def test_full_size_properties(pc, hw):
     off = (fd, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 0.0, None, 2.0, 0.0, False, 1)
     u, s = pc.apply_crt_effect(*off)
     assert torch.equal(u, fd)                                   # identity chain: u8 -> /255 -> *255 round trip
-    assert torch.equal(s, fd.float() / 255.0)
+    assert np.array_equal(s.cpu().numpy(), frame.numpy().astype(np.float32) / 255.0)   # true division (torch's GPU x/255 is x*(1/255))
     # aberration only: an exact wrap-around shift of R and B (integer indexing)
     a = list(off)
     a[5] = 3
