@@ -10,7 +10,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libcrtfx.so")
+LIB_PATH = os.environ.get("CRTFX_LIB") or os.path.join(_HERE, "libcrtfx.so")   # CRTFX_LIB: dev A/B builds only
 SOURCES = [os.path.join(_HERE, "csrc", "crtfx.hip"), os.path.join(_HERE, "csrc", "crtfx_kernels.hip.h"),
            os.path.join(ROOT, "include", "crtfx.h")]
 

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,8 +15,6 @@
 using namespace crtfx;
 
 namespace {
-
-constexpr int MAX_RADIUS = 64;   // ring of (NB + 2R) rows must fit LDS next to staging and LUTs
 
 struct DevBuf {
     void* p = nullptr;
@@ -30,9 +29,11 @@ struct crtfx_ctx {
     int pix_fmt = CRTFX_PIX_U8;
     bool params_set = false;
     KParams kp{};
-    DevBuf taps, triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
+    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
     float* pre = nullptr;            // H*W*3 float32 pre-warp scratch
     int seg_rows = 0;                // rows per k_phosphor block
+    unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
+    bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
     std::string err;
     // profiling
     bool prof = false;
@@ -130,20 +131,44 @@ struct ProfScope {
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-template <int RT>
-void launch_phosphor_t(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
-    const int strips = (c->W + TW - 1) / TW;
-    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
-    const size_t lds = phosphor_lds_bytes(c->kp.R);
-    hipLaunchKernelGGL((k_phosphor<RT>), dim3(strips, segs), dim3(K1_THREADS), lds, s, c->kp, kf, ko, c->seg_rows);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows) {
+    return ((size_t)rr_lds_fixed_floats(R) + (size_t)seg_rows * 3 + (size_t)seg_rows + 2 * R) * sizeof(float);
 }
 
+template <int RT>
+void launch_rr(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    const int strips = (c->W + TW - 1) / TW;
+    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
+    hipLaunchKernelGGL((k_phosphor_rr<RT>), dim3(strips, segs), dim3(RR_THREADS), phosphor_rr_lds_bytes(RT, c->seg_rows), s, c->kp, kf, ko, c->seg_rows);
+}
+
+void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    const int strips = (c->W + TW - 1) / TW;
+    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
+    hipLaunchKernelGGL((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, c->kp, kf, ko, c->seg_rows);
+}
+
+// Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
+// register-ring kernel; anything else (radius 0 = 1-tap copy, or > 12) the generic LDS-ring one.
 void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
     ProfScope ps(c, 0, s);
-    switch (c->kp.R) {
-        case 4: launch_phosphor_t<4>(c, kf, ko, s); break;    // sigma 1.2 / 1.5 (CLI default sigma, BASELINE config 2)
-        case 9: launch_phosphor_t<9>(c, kf, ko, s); break;    // sigma 3 (BASELINE config 3)
-        default: launch_phosphor_t<-1>(c, kf, ko, s); break;
+    // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in
+    const bool lean_ok = !c->force_generic && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane &&
+                         ko.blend == CRTFX_BLEND_NONE;
+    switch (lean_ok ? c->kp.R : -1) {
+        case 1: launch_rr<1>(c, kf, ko, s); break;
+        case 2: launch_rr<2>(c, kf, ko, s); break;
+        case 3: launch_rr<3>(c, kf, ko, s); break;
+        case 4: launch_rr<4>(c, kf, ko, s); break;
+        case 5: launch_rr<5>(c, kf, ko, s); break;
+        case 6: launch_rr<6>(c, kf, ko, s); break;
+        case 7: launch_rr<7>(c, kf, ko, s); break;
+        case 8: launch_rr<8>(c, kf, ko, s); break;
+        case 9: launch_rr<9>(c, kf, ko, s); break;
+        case 10: launch_rr<10>(c, kf, ko, s); break;
+        case 11: launch_rr<11>(c, kf, ko, s); break;
+        case 12: launch_rr<12>(c, kf, ko, s); break;
+        default: launch_generic(c, kf, ko, s); break;
     }
 }
 
@@ -160,8 +185,12 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         return fail(c, CRTFX_E_UNSUPPORTED, "grain_size > 1 is not built yet (SURVEY 8f row 3)");
     const KFrame kf = make_kframe(in, f);
     const bool warp = (fl & CRTFX_F_WARP) != 0;
+    // two-kernel path: warp on, or a persistence blend behind the bloom kernel (kept lean: the
+    // commit then runs in k_warp's epilogue with an identity map)
+    const bool two = warp || ((fl & CRTFX_F_BLOOM) && ko.blend != CRTFX_BLEND_NONE);
     KOut k1 = ko;
-    if (warp) { k1 = KOut{}; k1.pre = c->pre; }
+    if (two) { k1 = KOut{}; k1.pre = c->pre; }
+    k1.dbg = c->dbg;
     if (fl & CRTFX_F_BLOOM) {
         launch_phosphor(c, kf, k1, s);
     } else {
@@ -169,10 +198,10 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
         hipLaunchKernelGGL(k_point, grid, dim3(256), 0, s, c->kp, kf, k1);
     }
-    if (warp) {
+    if (two) {
         ProfScope ps(c, 1, s);
         dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-        hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, s, c->kp, (const float*)c->pre, ko, 0);
+        hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, s, c->kp, (const float*)c->pre, ko, warp ? 0 : 1);
     }
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
@@ -215,6 +244,10 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     seg = ((seg + NB - 1) / NB) * NB;
     if (seg > height) seg = ((height + NB - 1) / NB) * NB;
     c->seg_rows = seg;
+    const char* fg = getenv("CRTFX_FORCE_GENERIC");
+    c->force_generic = fg && fg[0] == '1';
+    const char* dp = getenv("CRTFX_DBG_PTR");
+    if (dp) c->dbg = reinterpret_cast<unsigned long long*>(strtoull(dp, nullptr, 0));
     *out_ctx = c;
     return CRTFX_OK;
 }
@@ -223,7 +256,7 @@ int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->taps, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap}) free_buf(*b);
+    for (DevBuf* b : {&c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
     delete c;
@@ -252,7 +285,6 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
 
     int rc;
     const int R = (fl & CRTFX_F_BLOOM) ? p->bloom_radius : 0;
-    if ((rc = upload(c, c->taps, p->bloom_taps, (fl & CRTFX_F_BLOOM) ? (2 * R + 1) * sizeof(float) : 0))) return rc;
     if ((rc = upload(c, c->triad_row, p->triad_row, (size_t)W * 3 * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_g, p->lut_g, LUT_N * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_inv, p->lut_inv, LUT_N * sizeof(float)))) return rc;
@@ -270,7 +302,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
     k.noise_scale = p->noise_scale; k.warp_k = p->warp_k; k.cx = p->warp_cx; k.cy = p->warp_cy;
     k.vig_strength = p->vignette_strength;
-    k.taps = (const float*)c->taps.p;
+    if (fl & CRTFX_F_BLOOM) std::memcpy(k.taps, p->bloom_taps, (2 * R + 1) * sizeof(float));
     k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
@@ -278,7 +310,6 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
     k.xmap = (const int*)c->xmap.p; k.ymap = (const int*)c->ymap.p;
-    if ((fl & CRTFX_F_BLOOM) && R == 0) k.flags |= 0;   // ksize 1: GaussianBlur copies; handled by taps = [1]
     c->kp = k;
     c->params_set = true;
 
@@ -287,8 +318,6 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         if (lds > 160 * 1024) return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d needs %zu B of LDS", R, lds);
         // opt in to > 64 KiB of dynamic LDS
         HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(c, hipFuncSetAttribute((const void*)k_phosphor<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return CRTFX_OK;
 }

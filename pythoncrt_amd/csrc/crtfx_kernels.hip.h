@@ -21,6 +21,9 @@
 
 namespace crtfx {
 
+constexpr int MAX_RADIUS = 64;            // bloom radius limit: ring of (NB + 2R) rows must fit LDS
+constexpr int MAX_TAPS = 2 * MAX_RADIUS + 1;
+
 // ---------------------------------------------------------------------------------------
 // kernel-side parameter blocks (passed by value as kernel arguments)
 // ---------------------------------------------------------------------------------------
@@ -35,7 +38,7 @@ struct KParams {
     float noise_scale;
     float warp_k, cx, cy;
     double vig_strength;
-    const float* __restrict__ taps;
+    float taps[MAX_TAPS];   // by value: lives in the kernarg segment -> scalar loads, provably invariant
     const float* __restrict__ triad_row;
     const float* __restrict__ triad_full;
     const float* __restrict__ lut_g;
@@ -65,6 +68,7 @@ struct KOut {
     float* state;        // persistence state in/out or nullptr
     int blend;           // crtfx_blend
     double p, q;         // persistence, 1 - persistence (double, as python computes them)
+    unsigned long long* dbg;   // CRTFX_STAMP diagnostic build only: per-wave phase cycle sums
 };
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
@@ -86,22 +90,39 @@ __device__ __forceinline__ float norm_u8(uint32_t u) {
     return fmaf(r, rcp, q);
 }
 
+// (x mod W) for x in [-8, W+8): |aberration| <= 8 (ref:1230), so one conditional add/subtract
+// replaces the integer division unless the image is narrower than the shift.
 __device__ __forceinline__ int wrap(int x, int W) {
+    if (W > 8) return x < 0 ? x + W : (x >= W ? x - W : x);
     x %= W;
     return x < 0 ? x + W : x;
 }
 
 // a1+a2(+a3): one RGB sample of the aberrated (and pixelated) float image; (y, x) in range.
 // ref:569-584 — R'[x] = R[(x-d) mod W], B'[x] = B[(x+d) mod W]; pixelate = index maps.
-__device__ __forceinline__ void fetch_rgb(const KParams& P, const uint8_t* __restrict__ in, int y, int x,
-                                          float& r, float& g, float& b) {
+struct RawRGB { uint32_t r, g, b; };
+// (y, x) already mapped through the pixelate index maps (or pixelate off): no dependent loads.
+__device__ __forceinline__ RawRGB fetch_raw_mapped(const KParams& P, const uint8_t* __restrict__ in, int y, int x) {
+    const uint8_t* row = in + (size_t)y * P.W * 3;
+    int xr = x, xb = x;
+    if (P.ab != 0) { xr = wrap(x - P.ab, P.W); xb = wrap(x + P.ab, P.W); }
+    RawRGB v;
+    v.r = row[xr * 3 + 0]; v.g = row[x * 3 + 1]; v.b = row[xb * 3 + 2];
+    return v;
+}
+__device__ __forceinline__ RawRGB fetch_raw(const KParams& P, const uint8_t* __restrict__ in, int y, int x) {
     if (P.flags & CRTFX_F_PIXELATE) { x = P.xmap[x]; y = P.ymap[y]; }
     const uint8_t* row = in + (size_t)y * P.W * 3;
     int xr = x, xb = x;
     if (P.ab != 0) { xr = wrap(x - P.ab, P.W); xb = wrap(x + P.ab, P.W); }
-    r = norm_u8(row[xr * 3 + 0]);
-    g = norm_u8(row[x * 3 + 1]);
-    b = norm_u8(row[xb * 3 + 2]);
+    RawRGB v;
+    v.r = row[xr * 3 + 0]; v.g = row[x * 3 + 1]; v.b = row[xb * 3 + 2];
+    return v;
+}
+__device__ __forceinline__ void fetch_rgb(const KParams& P, const uint8_t* __restrict__ in, int y, int x,
+                                          float& r, float& g, float& b) {
+    const RawRGB v = fetch_raw(P, in, y, x);
+    r = norm_u8(v.r); g = norm_u8(v.g); b = norm_u8(v.b);
 }
 
 // a4 — apply_color_adjustments (ref:279-305), float32 throughout.
@@ -150,24 +171,48 @@ __device__ __forceinline__ float grain_normal(uint32_t key0, uint32_t key1, uint
     return rad * __builtin_amdgcn_cosf(u2);                              // cos(2 pi u2)
 }
 
+// Per-pixel mask values of a7 (triad), a8 (scanline gain) and a9 (vignette), gathered by the
+// caller: k_point / the generic kernel load them per pixel, k_phosphor_rr keeps the per-column
+// ones in registers and the per-row ones in LDS.
+struct PixMasks {
+    float m0, m1, m2;   // triad mask RGB at this pixel
+    float sl;           // scanline gain
+    double vig;         // vignette gain (float64, ref:266-276)
+};
+
+__device__ __forceinline__ double vignette_gain(const KParams& P, double nx2, double ny2) {
+    return 1.0 - P.vig_strength * clip01(nx2 + ny2);                    // ref:274-275
+}
+
+__device__ __forceinline__ PixMasks load_masks(const KParams& P, const KFrame& F, int y, int x) {
+    PixMasks M{1.0f, 1.0f, 1.0f, 1.0f, 1.0};
+    if (P.flags & CRTFX_F_TRIAD) {
+        const float* m = P.triad_full ? P.triad_full + ((size_t)y * P.W + x) * 3 : P.triad_row + x * 3;
+        M.m0 = m[0]; M.m1 = m[1]; M.m2 = m[2];
+    }
+    if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_plane ? F.scan_plane[(size_t)y * P.W + x] : F.scan_row[y];
+    if (P.flags & CRTFX_F_VIGNETTE)
+        M.vig = P.vig_full ? P.vig_full[(size_t)y * P.W + x] : vignette_gain(P, P.vig_nx2[x], P.vig_ny2[y]);
+    return M;
+}
+
+// LUT index of ref:250 / :261: clip(trunc(clip(v,0,1) * 1024), 0, 1024).  clip(v) * 1024 lies
+// in [0, 1024] exactly, so the integer clip is the identity and is not re-applied.
+__device__ __forceinline__ int lut_index(float v) { return (int)(clip01(v) * 1024.0f); }
+
 // a7..a11 — from the post-bloom image to the pre-warp image.  The reference's image is float32
 // up to the scanline multiply and float64 from the vignette / flicker multiply on (NumPy
 // promotion); T mirrors that so the values agree before the single final narrowing.
-template <typename T>
-__device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, int y, int x,
+template <typename T, bool PLANES = true>
+__device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, int y, int x, const PixMasks& M,
                                            float r, float g, float b,
                                            const float* __restrict__ lut_g, const float* __restrict__ lut_inv,
                                            T& o0, T& o1, T& o2) {
     // a7 — _apply_triad_mask (ref:238-263)
     if (P.flags & CRTFX_F_TRIAD) {
-        const float* m = P.triad_full ? P.triad_full + ((size_t)y * P.W + x) * 3 : P.triad_row + x * 3;
-        const float m0 = m[0], m1 = m[1], m2 = m[2];
         if (P.flags & CRTFX_F_TRIAD_LUT) {
-            int i0 = min(max((int)(clip01(r) * 1024.0f), 0), 1024);
-            int i1 = min(max((int)(clip01(g) * 1024.0f), 0), 1024);
-            int i2 = min(max((int)(clip01(b) * 1024.0f), 0), 1024);
-            const float l0 = lut_g[i0], l1 = lut_g[i1], l2 = lut_g[i2];
-            float q0 = l0 * m0, q1 = l1 * m1, q2 = l2 * m2;
+            const float l0 = lut_g[lut_index(r)], l1 = lut_g[lut_index(g)], l2 = lut_g[lut_index(b)];
+            float q0 = l0 * M.m0, q1 = l1 * M.m1, q2 = l2 * M.m2;
             if (P.flags & CRTFX_F_TRIAD_LUMA) {
                 const float yb = (0.2126f * l0 + 0.7152f * l1) + 0.0722f * l2;
                 const float ya = (0.2126f * q0 + 0.7152f * q1) + 0.0722f * q2;
@@ -175,26 +220,17 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
                 ratio = fminf(fmaxf(ratio, 0.5f), 2.0f);
                 q0 *= ratio; q1 *= ratio; q2 *= ratio;
             }
-            i0 = min(max((int)(clip01(q0) * 1024.0f), 0), 1024);
-            i1 = min(max((int)(clip01(q1) * 1024.0f), 0), 1024);
-            i2 = min(max((int)(clip01(q2) * 1024.0f), 0), 1024);
-            r = clip01(lut_inv[i0]); g = clip01(lut_inv[i1]); b = clip01(lut_inv[i2]);
+            r = clip01(lut_inv[lut_index(q0)]); g = clip01(lut_inv[lut_index(q1)]); b = clip01(lut_inv[lut_index(q2)]);
         } else {
-            r = clip01(r * m0); g = clip01(g * m1); b = clip01(b * m2);
+            r = clip01(r * M.m0); g = clip01(g * M.m1); b = clip01(b * M.m2);
         }
     }
     // a8 — scanlines (ref:617-624)
-    if (P.flags & CRTFX_F_SCANLINES) {
-        const float sl = F.scan_plane ? F.scan_plane[(size_t)y * P.W + x] : F.scan_row[y];
-        r = clip01(r * sl); g = clip01(g * sl); b = clip01(b * sl);
-    }
+    if (P.flags & CRTFX_F_SCANLINES) { r = clip01(r * M.sl); g = clip01(g * M.sl); b = clip01(b * M.sl); }
     T v0 = (T)r, v1 = (T)g, v2 = (T)b;
-    // a9 — vignette (ref:266-276, 626-628); float64 mask
+    // a9 — vignette (ref:626-628): float64 mask promotes the image
     if (P.flags & CRTFX_F_VIGNETTE) {
-        double v;
-        if (P.vig_full) v = P.vig_full[(size_t)y * P.W + x];
-        else            v = 1.0 - P.vig_strength * clip01(P.vig_nx2[x] + P.vig_ny2[y]);
-        v0 = (T)clip01((double)v0 * v); v1 = (T)clip01((double)v1 * v); v2 = (T)clip01((double)v2 * v);
+        v0 = (T)clip01((double)v0 * M.vig); v1 = (T)clip01((double)v1 * M.vig); v2 = (T)clip01((double)v2 * M.vig);
     }
     // a10 — flicker (ref:630-633); np.float64 factor
     if (P.flags & CRTFX_F_FLICKER) {
@@ -203,7 +239,9 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
     // a11 — grain (ref:635-647): float32 noise * float32 scale, added in the image dtype
     if (P.flags & CRTFX_F_NOISE) {
         const uint32_t idx = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-        const float z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
+        float z;
+        if constexpr (PLANES) z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
+        else z = grain_normal(F.key0, F.key1, idx);
         const float n = z * P.noise_scale;
         v0 = clip01(v0 + (T)n); v1 = clip01(v1 + (T)n); v2 = clip01(v2 + (T)n);
     }
@@ -255,13 +293,15 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
 // a14 + a15 — commit epilogue shared by every kernel that produces final pixels.
 // T is the reference's image dtype at this point (double once promoted).
 // Returns the packed u8 pixel; stores the float outputs itself.
-template <typename T>
+template <typename T, bool BLEND = true>
 __device__ __forceinline__ uint32_t commit_pixel(const KOut& O, size_t pix, T v0, T v1, T v2) {
     if (O.out_f32) {
         float* p = O.out_f32 + pix * 3;
         p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2;
     }
-    if (O.blend == CRTFX_BLEND_RENDER) {           // ref:1092
+    if constexpr (!BLEND) {
+        // lean kernels: the host routes blended commits through k_commit / k_warp
+    } else if (O.blend == CRTFX_BLEND_RENDER) {           // ref:1092
         const float* s = O.state + pix * 3;
         const T p = (T)O.p, q = (T)O.q;
         v0 = clip01(p * (T)s[0] + q * v0); v1 = clip01(p * (T)s[1] + q * v1); v2 = clip01(p * (T)s[2] + q * v2);
@@ -284,28 +324,29 @@ __device__ __forceinline__ uint32_t commit_pixel(const KOut& O, size_t pix, T v0
 
 // One finished pre-warp pixel: either park it for k_warp or commit it.
 // Every lane of the wavefront must call this (store_row_u8 shuffles); `live` masks the pixel.
+template <bool LEAN = false>
 __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, const KOut& O, int y, int x0, int lane,
-                                           bool live, float r, float g, float b,
+                                           bool live, const PixMasks& M, float r, float g, float b,
                                            const float* lut_g, const float* lut_inv) {
     const int x = x0 + lane;
     const size_t pix = (size_t)y * P.W + x;
     uint32_t packed = 0;
     if (promotes(P)) {
         double v0 = 0, v1 = 0, v2 = 0;
-        if (live) tail_masks<double>(P, F, y, x, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
         if (O.pre) {
             if (live) { float* p = O.pre + pix * 3; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
             return;
         }
-        if (live) packed = commit_pixel<double>(O, pix, v0, v1, v2);
+        if (live) packed = commit_pixel<double, !LEAN>(O, pix, v0, v1, v2);
     } else {
         float v0 = 0, v1 = 0, v2 = 0;
-        if (live) tail_masks<float>(P, F, y, x, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (live) tail_masks<float, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
         if (O.pre) {
             if (live) { float* p = O.pre + pix * 3; p[0] = v0; p[1] = v1; p[2] = v2; }
             return;
         }
-        if (live) packed = commit_pixel<float>(O, pix, v0, v1, v2);
+        if (live) packed = commit_pixel<float, !LEAN>(O, pix, v0, v1, v2);
     }
     if (O.out_u8) {
         const int valid = min(64, P.W - x0);
@@ -330,8 +371,9 @@ __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     const int x = x0 + lane;
     const bool live = x < P.W;
     float r = 0, g = 0, b = 0;
-    if (live) { fetch_rgb(P, F.in, y, x, r, g, b); grade(P, r, g, b); }
-    emit_pixel(P, F, O, y, x0, lane, live, r, g, b, lut, lut + LUT_STRIDE);
+    PixMasks M{};
+    if (live) { M = load_masks(P, F, y, x); fetch_rgb(P, F.in, y, x, r, g, b); grade(P, r, g, b); }
+    emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -371,7 +413,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
     if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
         for (int i = tid; i < LUT_N; i += K1_THREADS) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
     }
-    const float* __restrict__ taps = P.taps;
+    const float* taps = P.taps;                 // kernarg-resident
     const int ring_base = y_begin - R;          // ring slot of row y is (y - ring_base) % ring_rows
 
     for (int hb = y_begin - R; hb < y_end + R; hb += NB) {
@@ -422,10 +464,13 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
                 float acc[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[j] = 0.0f;
-                const int first = out_lo - R;    // first ring row needed
-                const int nread = jrows + 2 * R;
-                int slot = (first - ring_base) % ring_rows;
-                for (int rr = 0; rr < nread; ++rr) {
+                // Always sweep the full NB + 2R window (a compile-time trip count when RT >= 0, so the
+                // tap index rr - j is static and dead taps vanish).  When fewer than NB rows are due
+                // (first / last block of the segment) the extra ring rows are stale; they only feed
+                // accumulators of rows >= jrows, which are never read.
+                int slot = (out_lo - R - ring_base) % ring_rows;
+#pragma unroll
+                for (int rr = 0; rr < NB + 2 * R; ++rr) {
                     const float v = ring[(slot * 3 + c) * TW + lane];
                     slot = slot + 1 == ring_rows ? 0 : slot + 1;
 #pragma unroll
@@ -445,7 +490,9 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
                 const int x = x0 + lane;
                 const bool live = x < W;
                 float r = 0, g = 0, b = 0;
+                PixMasks M{};
                 if (live) {
+                    M = load_masks(P, F, y, x);
                     fetch_rgb(P, F.in, y, x, r, g, b);
                     grade(P, r, g, b);
                     // ref:611 img = clip(img + bloom_strength * blur)
@@ -453,12 +500,268 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
                     g = clip01(g + P.bloom_strength * blr[(j * 3 + 1) * TW + lane]);
                     b = clip01(b + P.bloom_strength * blr[(j * 3 + 2) * TW + lane]);
                 }
-                emit_pixel(P, F, O, y, x0, lane, live, r, g, b, lut, lut + LUT_STRIDE);
+                emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
             }
         }
         // next A overwrites stg (last read in B, two barriers ago); next B overwrites ring rows
         // older than this block's window; next C1 overwrites blr after the two barriers above.
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_phosphor_rr — the same stage chain as k_phosphor for a compile-time radius RT >= 1, built
+// around what the phase stamps showed (profiles/r01_phase_stamps.txt): the blur arithmetic is
+// ~12 % of the time; exposed memory latency in the two pointwise phases was 75 %.
+//
+//   * 256 threads.  Waves 0-2 own one colour channel each in the V pass; all four share the
+//     pointwise phases (the NB = 8 output rows of a block split 2-2-2-2).
+//   * V pass on a REGISTER window: thread (c = wave, lane = column) keeps the last 2R + NB
+//     H-pass values of its column in registers, appends NB rows per block, forms output row j
+//     from win[j .. j+2R] oldest first (the oracle's ColumnFilter order) and shifts the window
+//     down by NB (2R moves per 8(2R+1) FMAs).  Indices are compile-time constants.  The result
+//     overwrites the H-pass value it replaces in LDS (same thread, same address).
+//   * phase A is software-pipelined: the uint8 bytes of the NEXT block of rows are requested
+//     before the blur phases of the current block and consumed one iteration later.
+//   * centre pixels needed again by C2 (img + strength*blur) wait in a small LDS ring of packed
+//     bytes instead of being re-fetched; per-column constants (triad RGB, vignette nx^2) sit in
+//     registers, per-row ones (scanline gain, vignette ny^2) in LDS.
+// LDS at R = 9: staging 8.4 KB + rows 6 KB + LUTs 8.2 KB + centre ring 8 KB + row table ~1.5 KB.
+// ---------------------------------------------------------------------------------------
+#ifdef CRTFX_STAMP
+// Diagnostic build (tools/phase_profile.py): where does a block iteration spend its cycles?
+// Never quote this build's run time; read the shares.  Stamp values go only to O.dbg.
+#define STAMP(slot) do { unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+                         __builtin_amdgcn_sched_barrier(0); stamp_sum[slot] += t__ - stamp_last; stamp_last = t__; } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+#ifndef CRTFX_RR_WAVES
+#define CRTFX_RR_WAVES 4     // min waves per SIMD the register allocator must leave room for
+#endif
+
+constexpr int RR_THREADS = 256;
+
+__host__ __device__ constexpr int rr_pad(int R) { return (R + 3) & ~3; }
+__host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
+__host__ __device__ constexpr int rr_cring(int R) { int n = 1; while (n < R + 2 * NB) n <<= 1; return n; }
+// LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
+__host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * rr_swp(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW; }
+
+template <int RT>
+__global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KParams P, KFrame F, KOut O, int seg_rows) {
+    extern __shared__ float smem_raw[];
+    float* smem = static_cast<float*>(__builtin_assume_aligned(smem_raw, 16));
+    constexpr int R = RT, K = 2 * R + 1;
+    constexpr int pad = rr_pad(R);
+    constexpr int SWP = rr_swp(R);
+    constexpr int L = 2 * R + NB;               // register window length
+    constexpr int CR = rr_cring(R);             // centre ring rows (power of two >= R + 2 NB)
+    constexpr int A_ITEMS = (NB * SWP + RR_THREADS - 1) / RR_THREADS;
+    constexpr int B_ITEMS = (NB * 48 + RR_THREADS - 1) / RR_THREADS;
+    constexpr int HT = NB * 3 * TW;             // one H-row tile
+    float* stg = smem;                          // [NB][3][SWP]
+    float* hrow = stg + NB * 3 * SWP;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
+    float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
+    uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // [CR][TW] packed centre pixels
+    uint32_t* rowtab = cring + CR * TW;                                    // [seg_rows][3]: scan gain bits, ny2 lo, ny2 hi
+    int* ytab = reinterpret_cast<int*>(rowtab + seg_rows * 3);             // [seg_rows + 2R]: source row of halo row (pixelate)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int H = P.H, W = P.W;
+    const int x0 = blockIdx.x * TW;
+    const int y_begin = blockIdx.y * seg_rows;
+    const int y_end = min(H, y_begin + seg_rows);
+    if (y_begin >= H) return;
+    const uint32_t fl = P.flags;
+
+    if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT)) {
+        for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    }
+    // per-row table for this segment (the host only launches this kernel when no per-pixel
+    // plane — triad_full, scan_plane, vig_full, noise_plane — and no in-kernel blend is in play)
+    const bool row_scan = (fl & CRTFX_F_SCANLINES) != 0;
+    const bool row_vig = (fl & CRTFX_F_VIGNETTE) != 0;
+    for (int i = tid; i < y_end - y_begin; i += RR_THREADS) {
+        rowtab[i * 3] = __float_as_uint(row_scan ? F.scan_row[y_begin + i] : 1.0f);
+        const double n2 = row_vig ? P.vig_ny2[y_begin + i] : 0.0;
+        rowtab[i * 3 + 1] = (uint32_t)__double2loint(n2);
+        rowtab[i * 3 + 2] = (uint32_t)__double2hiint(n2);
+    }
+    const bool pixelate = (fl & CRTFX_F_PIXELATE) != 0;
+    if (pixelate)
+        for (int i = tid; i < y_end - y_begin + 2 * R; i += RR_THREADS) ytab[i] = P.ymap[min(max(y_begin - R + i, 0), H - 1)];
+    // per-column constants of this lane
+    const int xc = min(x0 + lane, W - 1);
+    float cm0 = 1.0f, cm1 = 1.0f, cm2 = 1.0f;
+    if (fl & CRTFX_F_TRIAD) { cm0 = P.triad_row[xc * 3]; cm1 = P.triad_row[xc * 3 + 1]; cm2 = P.triad_row[xc * 3 + 2]; }
+    const double cnx2 = row_vig ? P.vig_nx2[xc] : 0.0;
+
+    const float* taps = P.taps;
+    float win[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) win[i] = 0.0f;
+    const int hcol_off = min(wave, 2) * TW + lane;   // this thread's column in its channel plane
+#ifdef CRTFX_STAMP
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+
+    // A-phase item u of this thread: staging row j = it / SWP, column i = it % SWP (block-invariant).
+    // Its source column (BORDER_REPLICATE clamp, then the pixelate map) is resolved once here so
+    // that the loads issued inside the loop depend on no other vector-memory load: a dependent
+    // index load in fetch would put an s_waitcnt vmcnt(0) in front of every item's byte loads.
+    int xsrc[A_ITEMS];
+#pragma unroll
+    for (int u = 0; u < A_ITEMS; ++u) {
+        const int it = tid + u * RR_THREADS;
+        const int i = it - (it / SWP) * SWP;
+        const int x = min(max(x0 - pad + i, 0), W - 1);
+        xsrc[u] = pixelate ? P.xmap[x] : x;
+    }
+    __syncthreads();                                // ytab / rowtab / lut visible
+    RawRGB raw[A_ITEMS];
+    auto prefetch = [&](int hb) {
+        const int nrows = min(NB, y_end + R - hb);
+#pragma unroll
+        for (int u = 0; u < A_ITEMS; ++u) {
+            const int it = tid + u * RR_THREADS;
+            const int j = it / SWP;
+            if (j < nrows) {
+                const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
+                raw[u] = fetch_raw_mapped(P, F.in, y, xsrc[u]);
+            }
+        }
+    };
+    // C2 of the block whose first H-row is hbp: output rows [hbp - R, hbp - R + NB) from tile `ht`
+    auto phase_c2 = [&](int hbp, const float* ht) {
+        const int x = x0 + lane;
+        const bool xin = x < W;
+#pragma unroll 1
+        for (int j = wave; j < NB; j += 4) {                  // wave w handles rows w and w + 4
+            const int y = hbp - R + j;
+            if (y >= y_begin && y < y_end) {                  // wave-uniform
+                float r = 0, g = 0, b = 0;
+                PixMasks M{cm0, cm1, cm2, 1.0f, 1.0};
+                if (xin) {
+                    const uint32_t pk = cring[((y - (y_begin - R)) & (CR - 1)) * TW + lane];
+                    const uint32_t* rt = rowtab + (y - y_begin) * 3;
+                    M.sl = __uint_as_float(rt[0]);
+                    if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
+                    r = norm_u8(pk & 255u); g = norm_u8((pk >> 8) & 255u); b = norm_u8((pk >> 16) & 255u);
+                    grade(P, r, g, b);
+                    r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
+                    g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
+                    b = clip01(b + P.bloom_strength * ht[(j * 3 + 2) * TW + lane]);
+                }
+                emit_pixel<true>(P, F, O, y, x0, lane, xin, M, r, g, b, lut, lut + LUT_STRIDE);
+            }
+        }
+    };
+
+    // Phase pairing per block n (first H-row hb, tile t = n & 1):
+    //     { C1(n-1), A(n) }  barrier  { C2(n-1), B(n) }  barrier
+    // The stores of C2(n-1) then have the whole of B(n) + C1(n) + A(n+1) to retire before the next
+    // s_waitcnt vmcnt (the prefetched bytes of A(n+1)): vmcnt counts loads and stores in one
+    // in-order queue, so a wait placed right behind the stores would expose their latency.
+    prefetch(y_begin - R);
+    int t = 0;
+    for (int hb = y_begin - R; hb < y_end + R; hb += NB, t ^= 1) {
+        const int nrows = min(NB, y_end + R - hb);
+        float* ht = hrow + t * HT;
+        // ---- C1(n-1): vertical pass on the register window; row j = blur of output row hb-NB-R+j ----
+        if (hb > y_begin - R && wave < 3) {
+            float* hcol = hrow + (t ^ 1) * HT + hcol_off;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], taps[k], acc);
+                hcol[j * 3 * TW] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * R; ++i) win[i] = win[i + NB];
+        }
+        STAMP(4);
+        // ---- A(n): grade the prefetched halo rows [hb, hb+nrows) into the staging tile ----------
+#pragma unroll
+        for (int u = 0; u < A_ITEMS; ++u) {
+            const int it = tid + u * RR_THREADS;
+            const int j = it / SWP, i = it - j * SWP;
+            if (j < nrows) {
+                if (i >= pad && i < pad + TW)       // centre column: park the packed bytes for C2
+                    cring[((hb + j - (y_begin - R)) & (CR - 1)) * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
+                float r = norm_u8(raw[u].r), g = norm_u8(raw[u].g), b = norm_u8(raw[u].b);
+                grade(P, r, g, b);
+                float* s = stg + (j * 3) * SWP + i;
+                s[0] = bloom_src(P, r); s[SWP] = bloom_src(P, g); s[2 * SWP] = bloom_src(P, b);
+            }
+        }
+        if (hb + NB < y_end + R) prefetch(hb + NB);     // in flight across C2 / B / C1
+        STAMP(0);
+        __syncthreads();
+        STAMP(1);
+        // ---- C2(n-1): combine + masks + store -----------------------------------------------------
+        if (hb > y_begin - R) phase_c2(hb - NB, hrow + (t ^ 1) * HT);
+        STAMP(6);
+        // ---- B(n): horizontal pass -> tile t ----------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < B_ITEMS; ++u) {
+            const int it = tid + u * RR_THREADS;
+            const int j = it / 48, rem = it - j * 48;
+            if (j < nrows) {
+                const int c = rem >> 4, gq = rem & 15;
+                const float4* srow = reinterpret_cast<const float4*>(stg + (j * 3 + c) * SWP) + gq;
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                constexpr int off = pad - R;
+#pragma unroll
+                for (int qq = 0; qq < (2 * pad + 4) / 4; ++qq) {
+                    const float4 v = srow[qq];
+                    const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int tt = 4 * qq + e - i - off;
+                            if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], taps[tt], acc[i]);
+                        }
+                }
+                reinterpret_cast<float4*>(ht + (j * 3 + c) * TW)[gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
+    }
+    // ---- drain: C1 and C2 of the last block --------------------------------------------------------
+    {
+        const int hb_last = y_begin - R + ((y_end + R - (y_begin - R) - 1) / NB) * NB;
+        float* htl = hrow + (t ^ 1) * HT;
+        if (wave < 3) {
+            float* hcol = htl + hcol_off;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], taps[k], acc);
+                hcol[j * 3 * TW] = acc;
+            }
+        }
+        __syncthreads();
+        phase_c2(hb_last, htl);
+    }
+#ifdef CRTFX_STAMP
+    if (O.dbg && lane == 0) {
+        unsigned long long* d = O.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = stamp_sum[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
