@@ -11,8 +11,10 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CRTFX_LIB") or os.path.join(_HERE, "libcrtfx.so")   # CRTFX_LIB: dev A/B builds only
-SOURCES = [os.path.join(_HERE, "csrc", "crtfx.hip"), os.path.join(_HERE, "csrc", "crtfx_kernels.hip.h"),
-           os.path.join(ROOT, "include", "crtfx.h")]
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = [os.path.join(CSRC, f) for f in ("crtfx.hip", "crtfx_rr.hip", "crtfx_kernels.hip.h", "crtfx_internal.h")] + \
+          [os.path.join(ROOT, "include", "crtfx.h")]
+RR_RADII = tuple(range(1, 13))
 
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4
 PIX_U8, PIX_F16 = 0, 1
@@ -73,20 +75,35 @@ SYMBOLS = {
     "crtfx_host_blur_row": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
 }
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libcrtfx.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in SOURCES):
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile libcrtfx.so in-tree for gfx950 (hipcc cross-compiles without a GPU): crtfx.hip plus
+    crtfx_rr.hip once per radius, the translation units in parallel, then one link."""
+    out = out or LIB_PATH
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in SOURCES):
+        return out
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = "hipcc" if _which("hipcc") else "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(_HERE, "csrc"),
-           "-o", LIB_PATH, SOURCES[0]]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    return LIB_PATH
+    objdir = os.path.join(ROOT, "build", "obj", os.path.basename(out))
+    os.makedirs(objdir, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    jobs = [([hipcc, *HIPCC_FLAGS, *extra_flags, *inc, "-c", os.path.join(CSRC, "crtfx.hip"), "-o", os.path.join(objdir, "crtfx.o")])]
+    for r in RR_RADII:
+        jobs.append([hipcc, *HIPCC_FLAGS, *extra_flags, *inc, f"-DRR_R={r}", "-c", os.path.join(CSRC, "crtfx_rr.hip"),
+                     "-o", os.path.join(objdir, f"crtfx_rr_{r}.o")])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if not verbose else None)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        list(ex.map(run, jobs))
+    objs = [j[-1] for j in jobs]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
 
 
 def _which(name):

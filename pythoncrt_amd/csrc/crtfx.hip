@@ -9,8 +9,9 @@
 #include <string>
 #include <vector>
 
+#define CRTFX_MAIN_TU 1   // this TU owns the non-template kernels of crtfx_kernels.hip.h
 #include "crtfx.h"
-#include "crtfx_kernels.hip.h"
+#include "crtfx_internal.h"
 
 using namespace crtfx;
 
@@ -34,6 +35,7 @@ struct crtfx_ctx {
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
     bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
+    bool force_runtime_flags = false; // CRTFX_FORCE_RUNTIME_FLAGS=1: never take a gate-folded instantiation (tests)
     std::string err;
     // profiling
     bool prof = false;
@@ -135,13 +137,6 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows) {
     return ((size_t)rr_lds_fixed_floats(R) + (size_t)seg_rows * 3 + (size_t)seg_rows + 2 * R) * sizeof(float);
 }
 
-template <int RT>
-void launch_rr(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
-    const int strips = (c->W + TW - 1) / TW;
-    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
-    hipLaunchKernelGGL((k_phosphor_rr<RT>), dim3(strips, segs), dim3(RR_THREADS), phosphor_rr_lds_bytes(RT, c->seg_rows), s, c->kp, kf, ko, c->seg_rows);
-}
-
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
@@ -149,26 +144,23 @@ void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t 
 }
 
 // Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
-// register-ring kernel; anything else (radius 0 = 1-tap copy, or > 12) the generic LDS-ring one.
+// register-window kernel; anything else (radius 0 = 1-tap copy, or > 12) the generic LDS-ring one.
 void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr, rr_launch_1, rr_launch_2, rr_launch_3, rr_launch_4,
+                                                          rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
+                                                          rr_launch_10, rr_launch_11, rr_launch_12};
     ProfScope ps(c, 0, s);
     // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in
     const bool lean_ok = !c->force_generic && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane &&
                          ko.blend == CRTFX_BLEND_NONE;
-    switch (lean_ok ? c->kp.R : -1) {
-        case 1: launch_rr<1>(c, kf, ko, s); break;
-        case 2: launch_rr<2>(c, kf, ko, s); break;
-        case 3: launch_rr<3>(c, kf, ko, s); break;
-        case 4: launch_rr<4>(c, kf, ko, s); break;
-        case 5: launch_rr<5>(c, kf, ko, s); break;
-        case 6: launch_rr<6>(c, kf, ko, s); break;
-        case 7: launch_rr<7>(c, kf, ko, s); break;
-        case 8: launch_rr<8>(c, kf, ko, s); break;
-        case 9: launch_rr<9>(c, kf, ko, s); break;
-        case 10: launch_rr<10>(c, kf, ko, s); break;
-        case 11: launch_rr<11>(c, kf, ko, s); break;
-        case 12: launch_rr<12>(c, kf, ko, s); break;
-        default: launch_generic(c, kf, ko, s); break;
+    const int R = c->kp.R;
+    if (lean_ok && R >= 1 && R <= RR_MAX_RADIUS) {
+        const int strips = (c->W + TW - 1) / TW;
+        const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
+        const int variant = ((c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags) ? 1 : 0;
+        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs), phosphor_rr_lds_bytes(R, c->seg_rows), s, variant);
+    } else {
+        launch_generic(c, kf, ko, s);
     }
 }
 
@@ -246,6 +238,8 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     c->seg_rows = seg;
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
+    c->force_runtime_flags = fr && fr[0] == '1';
     const char* dp = getenv("CRTFX_DBG_PTR");
     if (dp) c->dbg = reinterpret_cast<unsigned long long*>(strtoull(dp, nullptr, 0));
     *out_ctx = c;

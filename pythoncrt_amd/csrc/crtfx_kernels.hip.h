@@ -357,6 +357,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
 // ---------------------------------------------------------------------------------------
 // k_point — bloom off: the chain is pointwise.  One thread per pixel, 4 rows x 64 px per block.
 // ---------------------------------------------------------------------------------------
+#ifdef CRTFX_MAIN_TU
 __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     __shared__ float lut[2 * LUT_STRIDE];
     const bool use_lut = (P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT);
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     if (live) { M = load_masks(P, F, y, x); fetch_rgb(P, F.in, y, x, r, g, b); grade(P, r, g, b); }
     emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
 }
+#endif  // CRTFX_MAIN_TU
 
 // ---------------------------------------------------------------------------------------
 // k_phosphor — grade + separable Gaussian bloom + masks + grain.
@@ -537,31 +539,50 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
 #endif
 
 #ifndef CRTFX_RR_WAVES
-#define CRTFX_RR_WAVES 4     // min waves per SIMD the register allocator must leave room for
+#define CRTFX_RR_WAVES 3     // min waves per SIMD the register allocator must leave room for (4 forces spills)
 #endif
 
 constexpr int RR_THREADS = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) volatile f32x4 lds_cv_f32x4;   // LDS-space, so the read stays a ds_ op
 
 __host__ __device__ constexpr int rr_pad(int R) { return (R + 3) & ~3; }
 __host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
+// staging row stride in floats: a multiple of 64 dwords, so the channel planes a ds_read_b128 lane
+// group straddles start on the same bank and its 16-byte slots stay disjoint (stride 88 cost ~2x).
+__host__ __device__ constexpr int rr_sws(int R) { return (rr_swp(R) + 63) & ~63; }
 __host__ __device__ constexpr int rr_cring(int R) { int n = 1; while (n < R + 2 * NB) n <<= 1; return n; }
 // LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
-__host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * rr_swp(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW; }
+__host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * rr_sws(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW; }
 
-template <int RT>
-__global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KParams P, KFrame F, KOut O, int seg_rows) {
-    extern __shared__ float smem_raw[];
-    float* smem = static_cast<float*>(__builtin_assume_aligned(smem_raw, 16));
+// SF: the stage gates (crtfx_params.flags without CRTFX_F_WARP, which k_phosphor never reads) as a
+// compile-time constant, or SF_RUNTIME.  With the gates folded the dead stages, their parameters
+// (SGPRs: the runtime-flag build spills ~450 v_readlane/v_writelane) and their branches vanish:
+// 178 -> 144 us per 4K frame at equal source.  The host picks the instantiation whose SF equals
+// the launch's flags, else the runtime-flag one.
+constexpr uint32_t SF_RUNTIME = 0xFFFFFFFFu;
+constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE;
+
+template <int RT, uint32_t SF>
+__global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KParams Pin, KFrame F, KOut O, int seg_rows) {
+    KParams P = Pin;
+    if constexpr (SF != SF_RUNTIME) P.flags = SF;
+    // declared as float4 so that the 16-byte alignment of the dynamic LDS base is part of the type:
+    // with a float[] base hipcc splits every 16-byte LDS access into ds_read2_b32/_b64 pairs, which
+    // at a 16-byte lane stride are 4-way / 2-way bank conflicts (ds_read_b128 is conflict-free).
+    extern __shared__ float4 smem4[];
+    float* smem = reinterpret_cast<float*>(smem4);
     constexpr int R = RT, K = 2 * R + 1;
     constexpr int pad = rr_pad(R);
     constexpr int SWP = rr_swp(R);
+    constexpr int SWS = rr_sws(R);
     constexpr int L = 2 * R + NB;               // register window length
     constexpr int CR = rr_cring(R);             // centre ring rows (power of two >= R + 2 NB)
     constexpr int A_ITEMS = (NB * SWP + RR_THREADS - 1) / RR_THREADS;
     constexpr int B_ITEMS = (NB * 48 + RR_THREADS - 1) / RR_THREADS;
     constexpr int HT = NB * 3 * TW;             // one H-row tile
-    float* stg = smem;                          // [NB][3][SWP]
-    float* hrow = stg + NB * 3 * SWP;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
+    float* stg = smem;                          // [NB][3][SWS] (SWP used)
+    float* hrow = stg + NB * 3 * SWS;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
     uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // [CR][TW] packed centre pixels
     uint32_t* rowtab = cring + CR * TW;                                    // [seg_rows][3]: scan gain bits, ny2 lo, ny2 hi
@@ -697,8 +718,8 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
                     cring[((hb + j - (y_begin - R)) & (CR - 1)) * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
                 float r = norm_u8(raw[u].r), g = norm_u8(raw[u].g), b = norm_u8(raw[u].b);
                 grade(P, r, g, b);
-                float* s = stg + (j * 3) * SWP + i;
-                s[0] = bloom_src(P, r); s[SWP] = bloom_src(P, g); s[2 * SWP] = bloom_src(P, b);
+                float* s = stg + (j * 3) * SWS + i;
+                s[0] = bloom_src(P, r); s[SWS] = bloom_src(P, g); s[2 * SWS] = bloom_src(P, b);
             }
         }
         if (hb + NB < y_end + R) prefetch(hb + NB);     // in flight across C2 / B / C1
@@ -715,13 +736,15 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
             const int j = it / 48, rem = it - j * 48;
             if (j < nrows) {
                 const int c = rem >> 4, gq = rem & 15;
-                const float4* srow = reinterpret_cast<const float4*>(stg + (j * 3 + c) * SWP) + gq;
+                // volatile: keeps each 16-byte read whole (ds_read_b128); a plain float4 load is scalarised and
+                // re-merged into ds_read2_b32 pairs
+                const lds_cv_f32x4* srow = (const lds_cv_f32x4*)smem4 + ((j * 3 + c) * (SWS / 4) + gq);
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 constexpr int off = pad - R;
 #pragma unroll
                 for (int qq = 0; qq < (2 * pad + 4) / 4; ++qq) {
-                    const float4 v = srow[qq];
-                    const float ve[4] = {v.x, v.y, v.z, v.w};
+                    const f32x4 v = srow[qq];
+                    const float ve[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -730,7 +753,7 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
                             if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], taps[tt], acc[i]);
                         }
                 }
-                reinterpret_cast<float4*>(ht + (j * 3 + c) * TW)[gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                smem4[(NB * 3 * SWS + t * HT) / 4 + (j * 3 + c) * (TW / 4) + gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
         STAMP(2);
@@ -807,6 +830,7 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
     o2 = ((a[2] * (T)w00 + b[2] * (T)w01) + c[2] * (T)w10) + d[2] * (T)w11;
 }
 
+#ifdef CRTFX_MAIN_TU
 __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict__ pre, KOut O, int identity) {
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
@@ -831,8 +855,10 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
     }
     if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), packed);
 }
+#endif  // CRTFX_MAIN_TU
 
 // crtfx_warp_map — the integer sampling map alone (parity: bit-exact against the oracle).
+#ifdef CRTFX_MAIN_TU
 __global__ void k_warp_map(KParams P, int* __restrict__ ix_out, int* __restrict__ iy_out, int* __restrict__ fxy_out) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -842,15 +868,19 @@ __global__ void k_warp_map(KParams P, int* __restrict__ ix_out, int* __restrict_
     const size_t i = (size_t)y * P.W + x;
     ix_out[i] = ix; iy_out[i] = iy; fxy_out[i] = (fy << 5) | fx;
 }
+#endif  // CRTFX_MAIN_TU
 
 // crtfx_noise_plane — the RNG's N(0,1) draw for every pixel of a frame.
+#ifdef CRTFX_MAIN_TU
 __global__ void k_noise_plane(int n, uint32_t key0, uint32_t key1, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = grain_normal(key0, key1, (uint32_t)i);
 }
+#endif  // CRTFX_MAIN_TU
 
 // crtfx_blend_quantise / crtfx_halo_correct_quantise — commit step on an existing float image.
 // mode 0: blend per O.blend.  mode 1: v = clip(local + coeff*carry) (frame-sharded halo fix-up).
+#ifdef CRTFX_MAIN_TU
 __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __restrict__ src, const float* __restrict__ carry,
                                                 double coeff, KOut O, int mode) {
     const int lane = threadIdx.x & 63;
@@ -874,5 +904,6 @@ __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __res
     }
     if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * W + x0) * 3, lane, min(64, W - x0), packed);
 }
+#endif  // CRTFX_MAIN_TU
 
 }  // namespace crtfx

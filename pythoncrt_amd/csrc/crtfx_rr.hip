@@ -1,0 +1,22 @@
+// crtfx_rr.hip — instantiations of k_phosphor_rr for ONE radius (-DRR_R=n): the gate-folded
+// full-chain variant and the runtime-flag variant.  Compiled once per radius, in parallel.
+#include "crtfx_internal.h"
+
+#ifndef RR_R
+#error "compile with -DRR_R=<radius 1..12>"
+#endif
+
+namespace crtfx {
+
+#define CRTFX_CAT2(a, b) a##b
+#define CRTFX_CAT(a, b) CRTFX_CAT2(a, b)
+
+void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KFrame& kf, const KOut& ko, int seg_rows, dim3 grid, size_t lds,
+                                 hipStream_t s, int variant) {
+    if (variant == 1)
+        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_FULL>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
+    else
+        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_RUNTIME>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
+}
+
+}  // namespace crtfx

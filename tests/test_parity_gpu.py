@@ -358,3 +358,29 @@ def test_1080p_frame_against_oracle(pc):
     assert np.abs(gotw.astype(np.float64) - expw).max() <= 3e-7
     d = np.abs(orc.convert_scale_abs(gotw).astype(np.int16) - orc.convert_scale_abs(expw).astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_kernel_variants_agree(pc, monkeypatch):
+    """The three k_phosphor builds of one launch — gate-folded register-window kernel, its
+    runtime-flag instantiation, and the generic LDS-ring kernel — give identical bits."""
+    from pythoncrt_amd import effects
+    h, w = 150, 200
+    frame = make_frame(h, w, seed=60, kind="grad")
+    tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    outs = {}
+    for name, env in (("folded", {}), ("runtime_flags", {"CRTFX_FORCE_RUNTIME_FLAGS": "1"}), ("generic", {"CRTFX_FORCE_GENERIC": "1"})):
+        for k in ("CRTFX_FORCE_RUNTIME_FLAGS", "CRTFX_FORCE_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        effects._tls.engines = {}          # the switches are read when a ctx is created
+        res = []
+        for sigma in (3.0, 1.2, 2.0):
+            a = (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 2.0, 1.25, False, 1, 0, 0.0)
+            res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3))
+            res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3, warp_strength=0.15))
+        outs[name] = res
+    effects._tls.engines = {}
+    for name in ("runtime_flags", "generic"):
+        for x, y in zip(outs["folded"], outs[name]):
+            assert np.array_equal(x, y), name
