@@ -133,8 +133,29 @@ struct ProfScope {
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows) {
-    return ((size_t)rr_lds_fixed_floats(R) + (size_t)seg_rows * 3 + (size_t)seg_rows + 2 * R) * sizeof(float);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate);
+
+// Rows per k_phosphor block.  Every block of the grid should be resident at once (a second,
+// partial round of blocks costs a whole extra block lifetime), so the grid is sized to the
+// number of block slots: blocks-per-CU (LDS-limited) x 256 CUs; and no shorter than 64 rows, to
+// keep the 2R rows of vertical halo recomputation per block small.
+int pick_seg_rows(int H, int W, int R) {
+    const int strips = (W + TW - 1) / TW;
+    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false);
+    int bpc = (int)(163840 / lds);
+    if (bpc > 4) bpc = 4;      // 4 waves per SIMD is what the register budget allows
+    if (bpc < 1) bpc = 1;
+    int segs = (bpc * 256) / strips;
+    if (segs < 1) segs = 1;
+    int seg = (H + segs - 1) / segs;
+    if (seg < 64) seg = 64;
+    seg = ((seg + NB - 1) / NB) * NB;
+    const int hmax = ((H + NB - 1) / NB) * NB;
+    return seg > hmax ? hmax : seg;
+}
+
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate) {
+    return ((size_t)rr_lds_fixed_floats(R) + (size_t)seg_rows * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -158,7 +179,7 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
         const int strips = (c->W + TW - 1) / TW;
         const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
         const int variant = ((c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags) ? 1 : 0;
-        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs), phosphor_rr_lds_bytes(R, c->seg_rows), s, variant);
+        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs), phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0), s, variant);
     } else {
         launch_generic(c, kf, ko, s);
     }
@@ -227,15 +248,7 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     if (!c) return CRTFX_E_NOMEM;
     c->device = device; c->H = height; c->W = width; c->pix_fmt = pix_fmt;
     if (hipMalloc((void**)&c->pre, (size_t)height * width * 3 * sizeof(float)) != hipSuccess) { delete c; return CRTFX_E_NOMEM; }
-    // rows per k_phosphor block: aim at >= ~4 blocks per CU over 256 CUs, but keep the vertical
-    // halo (2R extra H-pass rows per block) small: never shorter than 64 rows.
-    const int strips = (width + TW - 1) / TW;
-    int segs = (1024 + strips - 1) / strips;
-    int seg = (height + segs - 1) / segs;
-    if (seg < 64) seg = 64;
-    seg = ((seg + NB - 1) / NB) * NB;
-    if (seg > height) seg = ((height + NB - 1) / NB) * NB;
-    c->seg_rows = seg;
+    c->seg_rows = pick_seg_rows(height, width, 9);
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
@@ -306,6 +319,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.xmap = (const int*)c->xmap.p; k.ymap = (const int*)c->ymap.p;
     c->kp = k;
     c->params_set = true;
+    c->seg_rows = pick_seg_rows(H, W, R);
 
     if (fl & CRTFX_F_BLOOM) {
         const size_t lds = phosphor_lds_bytes(R);

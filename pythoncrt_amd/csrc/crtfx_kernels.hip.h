@@ -551,7 +551,7 @@ __host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
 // staging row stride in floats: a multiple of 64 dwords, so the channel planes a ds_read_b128 lane
 // group straddles start on the same bank and its 16-byte slots stay disjoint (stride 88 cost ~2x).
 __host__ __device__ constexpr int rr_sws(int R) { return (rr_swp(R) + 63) & ~63; }
-__host__ __device__ constexpr int rr_cring(int R) { int n = 1; while (n < R + 2 * NB) n <<= 1; return n; }
+__host__ __device__ constexpr int rr_cring(int R) { return R + 2 * NB; }   // exact: LDS is what caps blocks per CU
 // LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
 __host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * rr_sws(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW; }
 
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
     constexpr int SWP = rr_swp(R);
     constexpr int SWS = rr_sws(R);
     constexpr int L = 2 * R + NB;               // register window length
-    constexpr int CR = rr_cring(R);             // centre ring rows (power of two >= R + 2 NB)
+    constexpr int CR = rr_cring(R);             // centre ring rows: R + 2 NB
     constexpr int A_ITEMS = (NB * SWP + RR_THREADS - 1) / RR_THREADS;
     constexpr int B_ITEMS = (NB * 48 + RR_THREADS - 1) / RR_THREADS;
     constexpr int HT = NB * 3 * TW;             // one H-row tile
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
                 float r = 0, g = 0, b = 0;
                 PixMasks M{cm0, cm1, cm2, 1.0f, 1.0};
                 if (xin) {
-                    const uint32_t pk = cring[((y - (y_begin - R)) & (CR - 1)) * TW + lane];
+                    const uint32_t pk = cring[((y - (y_begin - R)) % CR) * TW + lane];
                     const uint32_t* rt = rowtab + (y - y_begin) * 3;
                     M.sl = __uint_as_float(rt[0]);
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
             const int j = it / SWP, i = it - j * SWP;
             if (j < nrows) {
                 if (i >= pad && i < pad + TW)       // centre column: park the packed bytes for C2
-                    cring[((hb + j - (y_begin - R)) & (CR - 1)) * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
+                    cring[((hb + j - (y_begin - R)) % CR) * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
                 float r = norm_u8(raw[u].r), g = norm_u8(raw[u].g), b = norm_u8(raw[u].b);
                 grade(P, r, g, b);
                 float* s = stg + (j * 3) * SWS + i;
@@ -806,6 +806,12 @@ __device__ __forceinline__ void warp_coords(const KParams& P, int y, int x, int&
     fx = sx & 31; fy = sy & 31;
 }
 
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };   // one RGB float pixel: a 12-byte, 4-aligned load
+
+// The four taps are loaded unconditionally from CLAMPED addresses (always inside the image) as
+// 12-byte vectors, all four in flight together; a tap that lies outside the image is then
+// replaced by the border value 0 (cv2.remap BORDER_CONSTANT), exactly what OpenCV's border
+// branch feeds into the same weighted sum.
 template <typename T>
 __device__ __forceinline__ void warp_sample(const KParams& P, const float* __restrict__ pre, int ix, int iy, int fx, int fy,
                                             T& o0, T& o1, T& o2) {
@@ -814,20 +820,22 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
     const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
     const bool xin0 = (unsigned)ix < (unsigned)P.W, xin1 = (unsigned)(ix + 1) < (unsigned)P.W;
     const bool yin0 = (unsigned)iy < (unsigned)P.H, yin1 = (unsigned)(iy + 1) < (unsigned)P.H;
-    T a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
-    if (yin0) {
-        const float* row = pre + (size_t)iy * P.W * 3;
-        if (xin0) { const float* p = row + (size_t)ix * 3; a[0] = p[0]; a[1] = p[1]; a[2] = p[2]; }
-        if (xin1) { const float* p = row + (size_t)(ix + 1) * 3; b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; }
-    }
-    if (yin1) {
-        const float* row = pre + (size_t)(iy + 1) * P.W * 3;
-        if (xin0) { const float* p = row + (size_t)ix * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
-        if (xin1) { const float* p = row + (size_t)(ix + 1) * 3; d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; }
-    }
-    o0 = ((a[0] * (T)w00 + b[0] * (T)w01) + c[0] * (T)w10) + d[0] * (T)w11;
-    o1 = ((a[1] * (T)w00 + b[1] * (T)w01) + c[1] * (T)w10) + d[1] * (T)w11;
-    o2 = ((a[2] * (T)w00 + b[2] * (T)w01) + c[2] * (T)w10) + d[2] * (T)w11;
+    const int xa = min(max(ix, 0), P.W - 1), xb = min(max(ix + 1, 0), P.W - 1);
+    const int ya = min(max(iy, 0), P.H - 1), yb = min(max(iy + 1, 0), P.H - 1);
+    const float* r0 = pre + (size_t)ya * P.W * 3;
+    const float* r1 = pre + (size_t)yb * P.W * 3;
+    const F3 A = *reinterpret_cast<const F3*>(r0 + xa * 3);
+    const F3 B = *reinterpret_cast<const F3*>(r0 + xb * 3);
+    const F3 C = *reinterpret_cast<const F3*>(r1 + xa * 3);
+    const F3 D = *reinterpret_cast<const F3*>(r1 + xb * 3);
+    const bool ka = xin0 && yin0, kb = xin1 && yin0, kc = xin0 && yin1, kd = xin1 && yin1;
+    const T a0 = ka ? (T)A.x : (T)0, a1 = ka ? (T)A.y : (T)0, a2 = ka ? (T)A.z : (T)0;
+    const T b0 = kb ? (T)B.x : (T)0, b1 = kb ? (T)B.y : (T)0, b2 = kb ? (T)B.z : (T)0;
+    const T c0 = kc ? (T)C.x : (T)0, c1 = kc ? (T)C.y : (T)0, c2 = kc ? (T)C.z : (T)0;
+    const T d0 = kd ? (T)D.x : (T)0, d1 = kd ? (T)D.y : (T)0, d2 = kd ? (T)D.z : (T)0;
+    o0 = ((a0 * (T)w00 + b0 * (T)w01) + c0 * (T)w10) + d0 * (T)w11;
+    o1 = ((a1 * (T)w00 + b1 * (T)w01) + c1 * (T)w10) + d1 * (T)w11;
+    o2 = ((a2 * (T)w00 + b2 * (T)w01) + c2 * (T)w10) + d2 * (T)w11;
 }
 
 #ifdef CRTFX_MAIN_TU
