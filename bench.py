@@ -93,38 +93,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from pythoncrt_amd.pipeline import FramePipeline, FrameShard, baseline_config, halo_exchange_correct
+    from pythoncrt_amd.pipeline import FramePipeline, GpuShardEngine, baseline_config
+    from pythoncrt_amd.shard import FrameShard, ShardedRender
     rs, h, w = baseline_config(a.config)
     fps = 30.0
     B = a.batch or (16 if h >= 2160 else 32)
     pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234)
     frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank)
-    out = torch.empty_like(frames)
     p = rs.persistence
     shard = FrameShard(world, rank, B)
-    local_states = torch.empty((B, h, w, 3), dtype=torch.float32, device=device) if (p > 0 and world > 1) else None
-    zero_state = torch.zeros((h, w, 3), dtype=torch.float32, device=device) if local_states is not None else None
+    engine = GpuShardEngine(pipe, B)
+    render = ShardedRender(shard, p, engine, dist=dist)
 
-    # frame indices: step s, rank r owns global frames [(s*world + r)*B, ... + B)
-    def records(step):
-        return pipe.frame_records((step * world + rank) * B, B)
+    # step s = round s of the frame-sharded render: rank r owns global frames [(s*world + r)*B, ... + B)
+    for s_ in range(a.warmup + a.steps):     # host-side per-frame tables are built outside the timed region
+        engine.records[(s_ * world + rank) * B] = pipe.frame_records((s_ * world + rank) * B, B)
 
-    recs = [records(s) for s in range(a.warmup + a.steps)]     # host-side tables built outside the timed region
-    carry = None
-    state = None
-
-    def one_step(s):
-        nonlocal carry, state
-        if local_states is not None:
-            st = zero_state.clone()
-            pipe.run(frames, state=st, out=out, records=recs[s], local_states=local_states)
-            carry = halo_exchange_correct(pipe, shard, local_states, out, s * world + rank, carry)
-            if world > 1:       # last rank's true final state seeds rank 0's next round
-                t = carry if rank == world - 1 else torch.empty_like(zero_state)
-                dist.broadcast(t, src=world - 1)
-                carry = t
-        else:
-            _, state = pipe.run(frames, state=state, out=out, records=recs[s])
+    def one_step(s_):
+        render.run_round(frames, s_)
 
     def sync():
         torch.cuda.synchronize(device)

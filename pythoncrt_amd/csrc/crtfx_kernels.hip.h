@@ -294,19 +294,19 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
 // T is the reference's image dtype at this point (double once promoted).
 // Returns the packed u8 pixel; stores the float outputs itself.
 template <typename T, bool BLEND = true>
-__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, size_t pix, T v0, T v1, T v2) {
+__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, uint32_t pix, T v0, T v1, T v2) {
     if (O.out_f32) {
-        float* p = O.out_f32 + pix * 3;
+        float* p = O.out_f32 + pix * 3u;
         p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2;
     }
     if constexpr (!BLEND) {
         // lean kernels: the host routes blended commits through k_commit / k_warp
     } else if (O.blend == CRTFX_BLEND_RENDER) {           // ref:1092
-        const float* s = O.state + pix * 3;
+        const float* s = O.state + pix * 3u;
         const T p = (T)O.p, q = (T)O.q;
         v0 = clip01(p * (T)s[0] + q * v0); v1 = clip01(p * (T)s[1] + q * v1); v2 = clip01(p * (T)s[2] + q * v2);
     } else if (O.blend == CRTFX_BLEND_PREVIEW) {   // ref:693 addWeighted = fma(prev, a, img*b)
-        const float* s = O.state + pix * 3;
+        const float* s = O.state + pix * 3u;
         const T p = (T)O.p, q = (T)O.q;
         if constexpr (sizeof(T) == 8) {
             v0 = fma((T)s[0], p, v0 * q); v1 = fma((T)s[1], p, v1 * q); v2 = fma((T)s[2], p, v2 * q);
@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t commit_pixel(const KOut& O, size_t pix, T v0
     }
     const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
     if (O.state) {
-        float* s = O.state + pix * 3;
+        float* s = O.state + pix * 3u;
         s[0] = f0; s[1] = f1; s[2] = f2;
     }
     return quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16);
@@ -329,13 +329,13 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
                                            bool live, const PixMasks& M, float r, float g, float b,
                                            const float* lut_g, const float* lut_inv) {
     const int x = x0 + lane;
-    const size_t pix = (size_t)y * P.W + x;
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     uint32_t packed = 0;
     if (promotes(P)) {
         double v0 = 0, v1 = 0, v2 = 0;
         if (live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
         if (O.pre) {
-            if (live) { float* p = O.pre + pix * 3; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
+            if (live) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
             return;
         }
         if (live) packed = commit_pixel<double, !LEAN>(O, pix, v0, v1, v2);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
         float v0 = 0, v1 = 0, v2 = 0;
         if (live) tail_masks<float, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
         if (O.pre) {
-            if (live) { float* p = O.pre + pix * 3; p[0] = v0; p[1] = v1; p[2] = v2; }
+            if (live) { float* p = O.pre + pix * 3u; p[0] = v0; p[1] = v1; p[2] = v2; }
             return;
         }
         if (live) packed = commit_pixel<float, !LEAN>(O, pix, v0, v1, v2);
@@ -822,12 +822,13 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
     const bool yin0 = (unsigned)iy < (unsigned)P.H, yin1 = (unsigned)(iy + 1) < (unsigned)P.H;
     const int xa = min(max(ix, 0), P.W - 1), xb = min(max(ix + 1, 0), P.W - 1);
     const int ya = min(max(iy, 0), P.H - 1), yb = min(max(iy + 1, 0), P.H - 1);
-    const float* r0 = pre + (size_t)ya * P.W * 3;
-    const float* r1 = pre + (size_t)yb * P.W * 3;
-    const F3 A = *reinterpret_cast<const F3*>(r0 + xa * 3);
-    const F3 B = *reinterpret_cast<const F3*>(r0 + xb * 3);
-    const F3 C = *reinterpret_cast<const F3*>(r1 + xa * 3);
-    const F3 D = *reinterpret_cast<const F3*>(r1 + xb * 3);
+    // 32-bit element offsets (H, W <= 32767 at 3 floats per pixel stay below 2^32): one 64-bit
+    // add per tap instead of 64-bit multiplies
+    const uint32_t rowa = (uint32_t)ya * (uint32_t)P.W, rowb = (uint32_t)yb * (uint32_t)P.W;
+    const F3 A = *reinterpret_cast<const F3*>(pre + (rowa + (uint32_t)xa) * 3u);
+    const F3 B = *reinterpret_cast<const F3*>(pre + (rowa + (uint32_t)xb) * 3u);
+    const F3 C = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xa) * 3u);
+    const F3 D = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xb) * 3u);
     const bool ka = xin0 && yin0, kb = xin1 && yin0, kc = xin0 && yin1, kd = xin1 && yin1;
     const T a0 = ka ? (T)A.x : (T)0, a1 = ka ? (T)A.y : (T)0, a2 = ka ? (T)A.z : (T)0;
     const T b0 = kb ? (T)B.x : (T)0, b1 = kb ? (T)B.y : (T)0, b2 = kb ? (T)B.z : (T)0;
@@ -846,17 +847,17 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
     if (y >= P.H) return;
     const int x = x0 + lane;
     const bool live = x < P.W;
-    const size_t pix = (size_t)y * P.W + x;
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     uint32_t packed = 0;
     if (live) {
         if (promotes(P)) {
             double v0, v1, v2;
-            if (identity) { const float* p = pre + pix * 3; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            if (identity) { const float* p = pre + pix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
             else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
             packed = commit_pixel<double>(O, pix, v0, v1, v2);
         } else {
             float v0, v1, v2;
-            if (identity) { const float* p = pre + pix * 3; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            if (identity) { const float* p = pre + pix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
             else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<float>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
             packed = commit_pixel<float>(O, pix, v0, v1, v2);
         }
@@ -897,12 +898,12 @@ __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __res
     if (y >= H) return;
     const int x = x0 + lane;
     const bool live = x < W;
-    const size_t pix = (size_t)y * W + x;
+    const uint32_t pix = (uint32_t)y * (uint32_t)W + (uint32_t)x;
     uint32_t packed = 0;
     if (live) {
-        const float* p = src + pix * 3;
+        const float* p = src + pix * 3u;
         if (mode == 1) {
-            const float* c = carry + pix * 3;
+            const float* c = carry + pix * 3u;
             const float cf = (float)coeff;
             const float v0 = clip01(p[0] + cf * c[0]), v1 = clip01(p[1] + cf * c[1]), v2 = clip01(p[2] + cf * c[2]);
             packed = commit_pixel<float>(O, pix, v0, v1, v2);

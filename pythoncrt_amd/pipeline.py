@@ -8,9 +8,8 @@ run of frames is enqueued back to back on one GPU, and runs are sharded across G
 from __future__ import annotations
 
 import ctypes
-import math
-from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from dataclasses import dataclass
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -170,75 +169,34 @@ class FramePipeline:
 
 
 # ---------------------------------------------------------------------------------------
-# frame sharding across ranks
+# GPU engine for shard.ShardedRender: local scan = crtfx_process_batch from a zero
+# state, correction = crtfx_halo_correct_quantise per frame.
 # ---------------------------------------------------------------------------------------
 
-@dataclass
-class FrameShard:
-    """Contiguous chunks of `chunk` frames dealt round-robin: frame t -> rank (t // chunk) % world.
-    With persistence p > 0 each rank scans its chunk from a ZERO incoming state (local_t), and
-    the true state is local_t + p^(t - t0 + 1) * carry_in, carry_in being the previous chunk's
-    final state (ref:1092 is linear in the state; its clip is inactive for inputs in [0,1])."""
-    world: int
-    rank: int
-    chunk: int
+class GpuShardEngine:
+    def __init__(self, pipe: FramePipeline, chunk: int):
+        self.pipe = pipe
+        h, w = pipe.h, pipe.w
+        self.local = torch.empty((chunk, h, w, 3), dtype=torch.float32, device=pipe.device)
+        self.out = torch.empty((chunk, h, w, 3), dtype=torch.uint8, device=pipe.device)
+        self.zero = torch.zeros((h, w, 3), dtype=torch.float32, device=pipe.device)
+        self.records = {}
 
-    def owner(self, t: int) -> int:
-        return (t // self.chunk) % self.world
+    def local_scan(self, frames, first_index, clip_start):
+        n = frames.shape[0]
+        recs = self.records.pop(first_index, None)
+        if self.pipe.rs.persistence <= 0.0:
+            self.pipe.run(frames, first_index=first_index, out=self.out[:n], records=recs)
+            return None, self.out[:n]
+        state = None if clip_start else self.zero.clone()      # zero incoming state, blend from the first frame on
+        self.pipe.run(frames, first_index=first_index, state=state, out=self.out[:n], records=recs, local_states=self.local[:n])
+        return self.local[:n], self.out[:n]
 
-    def my_chunks(self, n_frames: int) -> List[Tuple[int, int]]:
-        out = []
-        c = 0
-        while c * self.chunk < n_frames:
-            if c % self.world == self.rank:
-                out.append((c * self.chunk, min(n_frames, (c + 1) * self.chunk)))
-            c += 1
-        return out
-
-    @staticmethod
-    def settle_frames(p: float, eps: float = 2.0 ** -24) -> int:
-        """Frames after which a unit error in the incoming state has decayed below eps."""
-        if p <= 0.0:
-            return 0
-        return int(math.ceil(math.log(eps) / math.log(p)))
-
-
-def halo_exchange_correct(pipe: FramePipeline, shard: FrameShard, local_states: torch.Tensor, out: torch.Tensor,
-                          chunk_index: int, carry_prev_round: Optional[torch.Tensor], group=None):
-    """One chunk's halo step: send my chunk-final local state to the ring successor, receive the
-    predecessor's, and re-quantise my frames with the p^j-weighted carry added.
-
-    local_states: (n, H, W, 3) float32 local scan of this chunk (zero incoming state).
-    carry_prev_round: for rank 0, the true final state of the last chunk of the previous round
-    (None for the very first chunk of the clip).
-    Returns this chunk's true final state (what the successor needs... plus what rank world-1
-    hands to rank 0 for the next round)."""
-    import torch.distributed as dist
-    p = float(pipe.rs.persistence)
-    n = local_states.shape[0]
-    w = shard.world
-    final_local = local_states[n - 1]
-    if w > 1:
-        recv = torch.empty_like(final_local)
-        ops = []
-        if shard.rank < w - 1:
-            ops.append(dist.P2POp(dist.isend, final_local.contiguous(), shard.rank + 1, group))
-        if shard.rank > 0:
-            ops.append(dist.P2POp(dist.irecv, recv, shard.rank - 1, group))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        carry = recv if shard.rank > 0 else carry_prev_round
-    else:
-        carry = carry_prev_round
-    if carry is None:
-        return final_local
-    stream = torch.cuda.current_stream(pipe.device).cuda_stream
-    true_final = torch.empty_like(final_local)
-    with torch.cuda.device(pipe.device):
-        for j in range(n):
-            coeff = p ** (j + 1)
-            rc = pipe.lib.crtfx_halo_correct_quantise(pipe.engine.ctx, local_states[j].data_ptr(), carry.data_ptr(), coeff,
-                                                      true_final.data_ptr() if j == n - 1 else None, out[j].data_ptr(), stream)
-            _lib.check(pipe.lib, pipe.engine.ctx, rc)
-    return true_final
+    def correct(self, local, carry, p, out):
+        pipe = self.pipe
+        stream = torch.cuda.current_stream(pipe.device).cuda_stream
+        with torch.cuda.device(pipe.device):
+            for j in range(local.shape[0]):
+                rc = pipe.lib.crtfx_halo_correct_quantise(pipe.engine.ctx, local[j].data_ptr(), carry.data_ptr(), p ** (j + 1),
+                                                          None, out[j].data_ptr(), stream)
+                _lib.check(pipe.lib, pipe.engine.ctx, rc)

@@ -1,0 +1,138 @@
+"""Frame sharding across ranks — one process per GPU.
+
+The reference parallelises over frames with a 2-thread pool and commits frames strictly in order
+because of the persistence IIR  state_t = clip(p*state_{t-1} + (1-p)*static_t)  (crt_filter.py
+ref:1015-1017, :1081-1105).  Static effects are independent per frame, so frames shard with no
+communication at all when persistence is 0.  With persistence p > 0 the only coupling is that
+first-order linear recurrence (its clip is inactive: both inputs lie in [0,1]), so
+
+    state_t = local_t + p^(t - t0 + 1) * carry_in
+
+where local_t is the scan of a chunk started from a ZERO incoming state at frame t0 and carry_in
+is the true final state of the previous chunk.  Each rank therefore
+
+  1. scans its own chunk locally (all the expensive work, fully parallel),
+  2. exchanges ONE float32 state frame with its ring neighbours (RCCL send/recv over one xGMI
+     link; gloo in the CPU tests) — never an all-reduce / all-gather,
+  3. re-quantises its frames with the p^j-weighted carry added.
+
+Chunks are dealt round-robin: chunk c (frames [c*B, (c+1)*B)) belongs to rank c % world and is
+processed in round c // world.  The module is engine-agnostic (the GPU engine lives in
+pipeline.py; the CPU tests plug the oracle in) and imports nothing GPU-specific.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+
+@dataclass
+class FrameShard:
+    world: int
+    rank: int
+    chunk: int      # B frames per chunk
+
+    def owner(self, t: int) -> int:
+        return (t // self.chunk) % self.world
+
+    def chunk_of(self, round_index: int) -> int:
+        return round_index * self.world + self.rank
+
+    def frame_range(self, round_index: int, n_frames: Optional[int] = None) -> Tuple[int, int]:
+        c = self.chunk_of(round_index)
+        lo, hi = c * self.chunk, (c + 1) * self.chunk
+        if n_frames is not None:
+            lo, hi = min(lo, n_frames), min(hi, n_frames)
+        return lo, hi
+
+    def rounds(self, n_frames: int) -> int:
+        chunks = (n_frames + self.chunk - 1) // self.chunk
+        return (chunks + self.world - 1) // self.world
+
+    def my_chunks(self, n_frames: int) -> List[Tuple[int, int]]:
+        return [r for r in (self.frame_range(i, n_frames) for i in range(self.rounds(n_frames))) if r[1] > r[0]]
+
+
+def settle_frames(p: float, eps: float = 2.0 ** -24) -> int:
+    """Frames after which a unit incoming state has decayed below eps: ceil(ln eps / ln p)."""
+    if p <= 0.0:
+        return 0
+    return int(math.ceil(math.log(eps) / math.log(p)))
+
+
+class ShardedRender:
+    """The per-round protocol.  `engine` provides
+
+        local_scan(frames, first_index, clip_start) -> (local_states float32 (n,H,W,3), out uint8 (n,H,W,3))
+            scan of the chunk from a zero incoming state (clip_start: the very first frame of the
+            clip passes through unblended, ref:1094-1095, and there is no carry at all)
+        correct(local_states, carry, p, out) -> None
+            out[j] = quantise(clip(local_states[j] + p^(j+1) * carry))
+
+    `dist` is torch.distributed (or None for world 1).  When p^B is below float32 epsilon the
+    chunk-final LOCAL state already equals the true one to rounding, so every rank forwards it
+    at once (one parallel hop per round); otherwise the true finals are forwarded down the ring
+    rank by rank (exact for any B, at the cost of a world-1 hop chain)."""
+
+    def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None):
+        self.shard, self.p, self.engine, self.dist, self.group = shard, float(persistence), engine, dist, group
+        self.carry_next_round: Optional[torch.Tensor] = None      # rank 0: true final of the previous round's last chunk
+        self.parallel_hop = self.p > 0.0 and (self.p ** shard.chunk) < 2.0 ** -24
+
+    def _send_recv(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
+        ops, recv = [], None
+        d = self.dist
+        if dst is not None and send is not None:
+            ops.append(d.P2POp(d.isend, send.contiguous(), dst, self.group))
+        if src is not None:
+            recv = torch.empty_like(recv_like)
+            ops.append(d.P2POp(d.irecv, recv, src, self.group))
+        if ops:
+            for r in d.batch_isend_irecv(ops):
+                r.wait()
+        return recv
+
+    def run_round(self, frames: torch.Tensor, round_index: int, has_frames: bool = True):
+        """frames: this rank's chunk for this round.  Returns the finished uint8 frames."""
+        sh, p = self.shard, self.p
+        c = sh.chunk_of(round_index)
+        first = c * sh.chunk
+        if not has_frames:
+            raise NotImplementedError("every rank must own a chunk in every round (pad the clip to world*chunk frames)")
+        local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
+        if p <= 0.0:
+            return out
+        w, r = sh.world, sh.rank
+        n = frames.shape[0]
+        final_local = local[n - 1]
+        carry = None
+        if w == 1:
+            carry = self.carry_next_round
+            true_final = final_local if carry is None else final_local + (p ** n) * carry
+            self.carry_next_round = true_final.clone()
+        elif self.parallel_hop:
+            # every rank forwards its chunk-final local state (== true state to float32 rounding)
+            got = self._send_recv(final_local, final_local, (r - 1) % w, (r + 1) % w)
+            if r == 0:
+                carry, self.carry_next_round = self.carry_next_round, got      # what arrived now seeds the next round
+            else:
+                carry = got
+            if c == 0:
+                carry = None
+        else:
+            # exact chain: true finals travel down the ring
+            if r == 0:
+                carry = None if c == 0 else self.carry_next_round
+                true_final = final_local if carry is None else final_local + (p ** n) * carry
+                self._send_recv(true_final, final_local, None, 1)
+                self.carry_next_round = self._send_recv(None, final_local, w - 1, None)
+            else:
+                carry = self._send_recv(None, final_local, r - 1, None)
+                true_final = final_local + (p ** n) * carry
+                self._send_recv(true_final, final_local, None, (r + 1) % w)
+        if carry is not None:
+            self.engine.correct(local, carry, p, out)
+        return out

@@ -384,3 +384,34 @@ def test_kernel_variants_agree(pc, monkeypatch):
     for name in ("runtime_flags", "generic"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
+
+
+def test_sharded_persistence_pieces_on_gpu():
+    """The GPU engine behind shard.ShardedRender: a chunk scanned from a ZERO incoming state and then
+    corrected with p^(j+1) * carry reproduces the in-order render of the same frames."""
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from pythoncrt_amd.pipeline import FramePipeline, GpuShardEngine, baseline_config
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rs, _, _ = baseline_config(4)                 # 1080p config-4 parameters (persistence 0.5) at a small size
+    h, w, B = 135, 240, 6
+    g = torch.Generator(device="cpu").manual_seed(3)
+    frames = torch.randint(0, 256, (2 * B, h, w, 3), dtype=torch.uint8, generator=g).to(dev)
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=11)
+    # in-order reference on the GPU: 2B frames, state threaded through; keep every state
+    states = torch.empty((2 * B, h, w, 3), dtype=torch.float32, device=dev)
+    seq_out, _ = pipe.run(frames, first_index=0, local_states=states)
+    # chunk 1 as a remote rank would do it
+    eng = GpuShardEngine(pipe, B)
+    local, out = eng.local_scan(frames[B:], first_index=B, clip_start=False)
+    carry = states[B - 1].clone()
+    eng.correct(local, carry, rs.persistence, out)
+    torch.cuda.synchronize()
+    d = (out.cpu().to(torch.int16) - seq_out[B:].cpu().to(torch.int16)).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3
+    true_states = local + torch.tensor([rs.persistence ** (j + 1) for j in range(B)], device=dev).view(B, 1, 1, 1) * carry
+    assert float((true_states - states[B:]).abs().max()) < 5e-7
+    # chunk 0 (clip start) needs no carry: identical to the in-order frames
+    local0, out0 = eng.local_scan(frames[:B], first_index=0, clip_start=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out0, seq_out[:B]) and torch.equal(local0, states[:B])

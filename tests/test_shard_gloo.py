@@ -1,0 +1,107 @@
+"""Frame-sharded render (pythoncrt_amd/shard.py) with world_size 2 over gloo on CPU: the
+schedule, the one-frame persistence carry and the p^j correction, with the CPU oracle plugged in
+as the per-frame engine.  The sharded result must equal the single-process in-order render
+(crt_filter.py ref:1081-1105) to float rounding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import crt_oracle as orc
+from pythoncrt_amd.shard import FrameShard, ShardedRender, settle_frames
+
+H, W = 24, 32
+PARAMS = dict(scanline_strength=0.6, triad_gamma=2.2, triad_preserve_luma=False, aberration_px=1, bloom_sigma=0.0,
+              bloom_strength=0.0, noise_strength=0.0, scanline_period_px=2.0, fast_bloom=False, pixel_size=1)
+FPS, SPEED = 30.0, 30.0
+
+
+def clip_frames(n):
+    rng = np.random.default_rng(42)
+    return [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(n)]
+
+
+def static_of(frame, i):
+    tm = orc.make_triad_mask(H, W, 0.35, 0.0)
+    return orc.apply_static_effects(frame, PARAMS["scanline_strength"], tm, 2.2, False, 1, 0.0, 0.0, 0.0, 0.0, None, 2.0,
+                                    (i / FPS) * SPEED, False, 1, 0, 0.0, time_sec=i / FPS)
+
+
+class OracleEngine:
+    """local_scan / correct of shard.ShardedRender on the CPU oracle."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def local_scan(self, frames, first_index, clip_start):
+        state = None if clip_start else np.zeros((H, W, 3), np.float32)
+        local, out = [], []
+        for j in range(frames.shape[0]):
+            st = static_of(frames[j].numpy(), first_index + j)
+            state, u8 = orc.persistence_blend(state, st, self.p)
+            local.append(np.asarray(state, np.float32))
+            out.append(u8)
+        return torch.from_numpy(np.stack(local)), torch.from_numpy(np.stack(out))
+
+    def correct(self, local, carry, p, out):
+        for j in range(local.shape[0]):
+            v = np.clip(local[j].numpy() + np.float32(p ** (j + 1)) * carry.numpy(), 0.0, 1.0)
+            out[j] = torch.from_numpy(orc.convert_scale_abs(v))
+
+
+def worker(rank, world, port, p, chunk, rounds, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = clip_frames(chunk * world * rounds)
+    shard = FrameShard(world, rank, chunk)
+    render = ShardedRender(shard, p, OracleEngine(p), dist=dist)
+    for r in range(rounds):
+        lo, hi = shard.frame_range(r)
+        mine = torch.from_numpy(np.stack(frames[lo:hi]))
+        out = render.run_round(mine, r)
+        np.save(os.path.join(outdir, f"out_{lo}.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("p,chunk,rounds", [(0.5, 3, 3), (0.5, 26, 2), (0.9, 5, 2), (0.0, 4, 2)])
+def test_two_rank_render_matches_sequential(tmp_path, p, chunk, rounds):
+    world = 2
+    n = chunk * world * rounds
+    mp.spawn(worker, args=(world, free_port(), p, chunk, rounds, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out_{lo}.npy") for lo in range(0, n, chunk)])
+    # single-process in-order render
+    frames = clip_frames(n)
+    state, exp = None, []
+    for i, f in enumerate(frames):
+        state, u8 = orc.persistence_blend(state, static_of(f, i), p)
+        exp.append(u8)
+    exp = np.stack(exp)
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
+    if p == 0.0:
+        assert np.array_equal(got, exp)
+
+
+def test_shard_plan():
+    sh = FrameShard(8, 3, 16)
+    assert sh.owner(0) == 0 and sh.owner(16 * 3) == 3 and sh.owner(16 * 11 + 5) == 3
+    assert sh.frame_range(0) == (48, 64) and sh.frame_range(1) == (176, 192)
+    assert sh.my_chunks(16 * 8 * 2) == [(48, 64), (176, 192)]
+    covered = sorted(t for r in range(8) for lo, hi in FrameShard(8, r, 16).my_chunks(300) for t in range(lo, hi))
+    assert covered == list(range(300))
+    assert settle_frames(0.5) == 24 and settle_frames(0.95) == 325 and settle_frames(0.0) == 0
+    assert ShardedRender(FrameShard(2, 0, 26), 0.5, None).parallel_hop and not ShardedRender(FrameShard(2, 0, 3), 0.5, None).parallel_hop
