@@ -168,7 +168,7 @@ def main():
                 "kernels_ms": {k: round(v[0], 4) for k, v in kt.items()}, "launches": {k: v[1] for k, v in kt.items()},
             }
         if world == 1 and a.cpu_frames != 0:
-            n_cpu = a.cpu_frames if a.cpu_frames > 0 else (3 if h >= 2160 else 10)
+            n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work
             v, secs = cpu_baseline(rs, h, w, fps, n_cpu)
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_cpu} frames of the same {w}x{h} workload through oracle/ (numpy + C restatement of the OpenCV ops), "

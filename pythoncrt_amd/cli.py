@@ -1,0 +1,160 @@
+"""Command line of the reference (crt_filter.py parse_args ref:1153-1207, clamps in main
+ref:1220-1267) over the GPU pipeline.
+
+Same flag names, defaults and clamps.  What differs is the container I/O, which is out of scope
+here (codec plumbing): frames are read and written as raw `rgb24` (H x W x 3 uint8,
+the wire format of the reference's own FFmpegRawReader, ref:489-502, and of its ffmpeg writer
+pipe), from a file or stdin/stdout, so the drop-in sits between two ffmpeg processes:
+
+    ffmpeg -i in.mp4 -f rawvideo -pix_fmt rgb24 - |
+      python -m pythoncrt_amd.cli --input - --width 1920 --height 1080 --fps 30 --output - [effect flags] |
+      ffmpeg -f rawvideo -pix_fmt rgb24 -s 1920x1080 -r 30 -i - out.mp4
+
+`--gui`, `--gpu`, `--nvenc-preset`, `--encoder`, `--decoder`, `--crf`, `--bitrate` and the `--text*`
+flags are accepted for compatibility and ignored (encode/decode/UI are not part of this path).
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+
+import numpy as np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="pythoncrt_amd.cli", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--input", type=str, default="")
+    p.add_argument("--output", type=str)
+    p.add_argument("--width", type=int, default=0)
+    p.add_argument("--height", type=int, default=0)
+    p.add_argument("--fps", type=int, default=0)
+    p.add_argument("--scanline-strength", type=float, default=0.6)
+    p.add_argument("--triad-strength", type=float, default=0.35)
+    p.add_argument("--triad-gamma", type=float, default=2.2)
+    p.add_argument("--triad-preserve-luma", action="store_true")
+    p.add_argument("--triad-softness", type=float, default=0.5)
+    p.add_argument("--aberration-px", type=int, default=1)
+    p.add_argument("--bloom-sigma", type=float, default=1.2)
+    p.add_argument("--bloom-strength", type=float, default=0.25)
+    p.add_argument("--bloom-threshold", type=float, default=0.0)
+    p.add_argument("--noise-strength", type=float, default=1.5)
+    p.add_argument("--vignette-strength", type=float, default=0.25)
+    p.add_argument("--persistence", type=float, default=0.2)
+    p.add_argument("--crf", type=int, default=18)
+    p.add_argument("--bitrate", type=int, default=0)
+    p.add_argument("--scanline-speed", type=float, default=30.0)
+    p.add_argument("--scanline-period", type=float, default=2.0)
+    p.add_argument("--fast-bloom", action="store_true")
+    p.add_argument("--no-fast-bloom", dest="fast_bloom", action="store_false")
+    p.set_defaults(fast_bloom=True)
+    p.add_argument("--pixel-size", type=int, default=2)
+    p.add_argument("--brightness", type=float, default=0.0)
+    p.add_argument("--contrast", type=float, default=1.0)
+    p.add_argument("--gamma", type=float, default=1.0)
+    p.add_argument("--saturation", type=float, default=1.0)
+    p.add_argument("--temperature", type=float, default=0.0)
+    p.add_argument("--flicker-strength", type=float, default=0.0)
+    p.add_argument("--flicker-hz", type=float, default=0.0)
+    p.add_argument("--grain-size", type=int, default=1)
+    p.add_argument("--scanline-angle", type=float, default=0.0)
+    p.add_argument("--scanline-thickness", type=float, default=1.0)
+    p.add_argument("--warp-strength", type=float, default=0.0)
+    p.add_argument("--text", type=str, default="")
+    p.add_argument("--text-font", type=str, default="")
+    p.add_argument("--text-size", type=int, default=36)
+    p.add_argument("--text-color", type=str, default="#FFFFFF")
+    p.add_argument("--text-x", type=int, default=32)
+    p.add_argument("--text-y", type=int, default=32)
+    p.add_argument("--text-after", action="store_true")
+    p.add_argument("--gpu", action="store_true")
+    p.add_argument("--nvenc-preset", type=str, default="p4")
+    p.add_argument("--encoder", type=str, default="auto", choices=["auto", "nvidia", "amd", "cpu"])
+    p.add_argument("--decoder", type=str, default="auto", choices=["auto", "nvidia", "amd", "intel", "cpu"])
+    p.add_argument("--glitch-amp", type=int, default=0)
+    p.add_argument("--glitch-height", type=float, default=0.0)
+    p.add_argument("--gui", action="store_true")
+    # not in the reference
+    p.add_argument("--batch", type=int, default=16, help="frames enqueued per GPU batch")
+    p.add_argument("--noise-seed", type=int, default=None, help="seed of the counter-based grain RNG (default: random)")
+    return p
+
+
+def settings_from_args(a):
+    """The clamps of main() (ref:1225-1266) -> RenderSettings."""
+    from .pipeline import RenderSettings
+    return RenderSettings(
+        scanline_strength=float(max(0.0, min(1.0, a.scanline_strength))),
+        triad_strength=float(max(0.0, min(1.0, a.triad_strength))),
+        triad_gamma=float(max(0.1, a.triad_gamma)),
+        triad_preserve_luma=bool(a.triad_preserve_luma),
+        triad_softness=float(max(0.0, a.triad_softness)),
+        aberration_px=int(max(-8, min(8, a.aberration_px))),
+        bloom_sigma=max(0.0, a.bloom_sigma),
+        bloom_strength=max(0.0, a.bloom_strength),
+        noise_strength=max(0.0, a.noise_strength),
+        vignette_strength=float(max(0.0, min(1.0, a.vignette_strength))),
+        persistence=float(max(0.0, min(0.95, a.persistence))),
+        scanline_speed_px_s=float(a.scanline_speed),
+        scanline_period_px=max(1.0, float(a.scanline_period)),
+        fast_bloom=bool(a.fast_bloom),
+        pixel_size=max(1, int(a.pixel_size)),
+        glitch_amp_px=max(0, int(a.glitch_amp)),
+        glitch_height_frac=float(max(0.0, min(1.0, a.glitch_height))),
+        bloom_threshold=float(max(0.0, min(1.0, a.bloom_threshold))),
+        brightness=float(a.brightness),
+        contrast=float(a.contrast),
+        gamma=float(max(1e-3, a.gamma)),
+        saturation=float(max(0.0, a.saturation)),
+        temperature=float(max(-1.0, min(1.0, a.temperature))),
+        flicker_strength=float(max(0.0, min(1.0, a.flicker_strength))),
+        flicker_hz=float(max(0.0, a.flicker_hz)),
+        grain_size=max(1, int(a.grain_size)),
+        scanline_angle=float(a.scanline_angle),
+        scanline_thickness=float(max(0.1, a.scanline_thickness)),
+        warp_strength=float(max(-1.0, min(1.0, a.warp_strength))),
+    )
+
+
+def main(argv=None) -> int:
+    a = build_parser().parse_args(argv)
+    if a.gui or not a.input:
+        raise SystemExit("the GUI is not part of this path; pass --input (raw rgb24 file or '-')")
+    if a.width <= 0 or a.height <= 0:
+        raise SystemExit("raw rgb24 input needs --width and --height")
+    if a.text:
+        raise SystemExit("--text: overlay rasterisation is not built yet (SURVEY 8f row 1)")
+    import os
+    import torch
+    from .pipeline import FramePipeline
+    rs = settings_from_args(a)
+    fps_out = int(a.fps) if a.fps and a.fps > 0 else 24            # ref:914
+    h, w = int(a.height), int(a.width)
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm device visible; pythoncrt_amd has no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    seed = a.noise_seed if a.noise_seed is not None else int.from_bytes(os.urandom(8), "little")
+    pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=seed)
+    fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
+    out_path = a.output if a.output else (a.input + "_crt.rgb" if a.input != "-" else "-")
+    fout = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
+    frame_bytes = h * w * 3
+    t0 = time.perf_counter()
+    state, index = None, 0
+    while True:
+        buf = fin.read(frame_bytes * a.batch)
+        n = len(buf) // frame_bytes
+        if n == 0:
+            break
+        frames = torch.frombuffer(bytearray(buf[: n * frame_bytes]), dtype=torch.uint8).view(n, h, w, 3).to(dev)
+        out, state = pipe.run(frames, first_index=index, state=state)
+        fout.write(out.cpu().numpy().tobytes())
+        index += n
+    if fout is not sys.stdout.buffer:
+        fout.close()
+    print(f"{index} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)      # ref:1269
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -73,6 +73,57 @@ def load_reference():
     return ns, cv2
 
 
+CLI_ARGVS = {
+    "defaults": ["--input", "x.mp4"],
+    "extremes_hi": ["--input", "x.mp4", "--scanline-strength", "5", "--triad-strength", "3", "--triad-gamma", "0.01", "--triad-softness", "-1",
+                    "--aberration-px", "40", "--bloom-sigma", "-2", "--bloom-strength", "-1", "--noise-strength", "-3", "--vignette-strength", "9",
+                    "--persistence", "0.99", "--scanline-period", "0.2", "--pixel-size", "0", "--gamma", "0", "--saturation", "-1",
+                    "--temperature", "4", "--flicker-strength", "7", "--flicker-hz", "-1", "--grain-size", "0", "--scanline-thickness", "0.01",
+                    "--warp-strength", "3", "--glitch-amp", "-5", "--glitch-height", "2", "--bloom-threshold", "1.5", "--crf", "99"],
+    "extremes_lo": ["--input", "x.mp4", "--scanline-strength", "-1", "--aberration-px", "-40", "--persistence", "-0.5", "--temperature", "-4",
+                    "--warp-strength", "-3", "--vignette-strength", "-1", "--bloom-threshold", "-1", "--crf", "1", "--no-fast-bloom",
+                    "--triad-preserve-luma", "--text-after", "--fps", "25", "--width", "640", "--height", "360"],
+}
+
+
+def dump_cli_fixture():
+    """parse_args (ref:1153-1207) and the clamps of main (ref:1220-1267): the flag table and what
+    main() hands to process_video for a few argv sets.  process_video / Path are recording stubs."""
+    import argparse
+    import json
+    import sys
+    tree = ast.parse(open(REF).read())
+    nodes = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("parse_args", "main")]
+    captured = {}
+
+    class FakePath:
+        def __init__(self, s): self.s = str(s); self.stem = "x"
+        def exists(self): return True
+        def with_name(self, n): return FakePath(n)
+        def __str__(self): return self.s
+
+    def process_video(**kw):
+        captured.clear()
+        captured.update({k: (str(v) if isinstance(v, FakePath) else v) for k, v in kw.items()})
+        return False
+
+    ns = {"argparse": argparse, "Path": FakePath, "time": time, "process_video": process_video,
+          "launch_gui": lambda: None, "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), "<reference cli>", "exec"), ns)
+    fixture = {"process_video_kwargs": {}}
+    old = sys.argv
+    try:
+        for name, argv in CLI_ARGVS.items():
+            sys.argv = ["crt_filter.py"] + argv
+            ns["main"]()
+            fixture["process_video_kwargs"][name] = dict(captured)
+        sys.argv = ["crt_filter.py"]
+        fixture["namespace_defaults"] = vars(ns["parse_args"]())
+    finally:
+        sys.argv = old
+    json.dump(fixture, open(os.path.join(OUT, "reference_cli.json"), "w"), indent=1, sort_keys=True)
+
+
 def frames(h, w):
     rng = np.random.default_rng(0)
     noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -210,6 +261,7 @@ def main():
     assert c[0] == "convertScaleAbs" and c[2] == 255.0 and c[3] == 0.0
     out["chain/48x64/noise/glitch_preview_float"] = c[1]
 
+    dump_cli_fixture()
     np.savez_compressed(os.path.join(OUT, "reference_numpy_stages.npz"), **out)
     total = sum(v.nbytes for v in out.values())
     print(f"wrote {len(out)} arrays, {total/1e6:.2f} MB raw")

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>_* (tools/collect_profiles.sh) into the tracked files under profiles/:
+<tag>_kernel_stats.csv, <tag>_pmc.json, <tag>_bench.json and profiles/traffic.json (HBM bytes per frame
+from the separate FETCH_SIZE / WRITE_SIZE passes; KiB -> bytes, not x2-corrected: see DESIGN.md 6)."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_z"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "config3"
+os.makedirs("profiles", exist_ok=True)
+ks = glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True)
+if ks:
+    rows = [r for r in csv.reader(open(ks[0]))]
+    keep = [rows[0]] + [r for r in rows[1:] if "crtfx" in r[0]]
+    csv.writer(open(f"profiles/{tag}_kernel_stats.csv", "w")).writerows(keep)
+pmc = {}
+for part in ("fetch", "write", "sq"):
+    fs = glob.glob(f"gpurun_out/{tag}_{part}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(fs[0])):
+        k = row["Kernel_Name"]
+        if "crtfx" in k:
+            agg[k.split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, d in agg.items():
+        pmc.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in d.items()})
+json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
+traffic = sum((d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 for d in pmc.values())
+tj = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
+tj[cfg] = int(traffic)
+tj[cfg + "_detail_bytes"] = {k: {c: int(v * 1024) for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")} for k, d in pmc.items()}
+json.dump(tj, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
+if os.path.exists(f"gpurun_out/{tag}_bench.json"):
+    shutil.copy(f"gpurun_out/{tag}_bench.json", f"profiles/{tag}_bench.json")
+print(json.dumps(tj, indent=1))
+print(open(f"profiles/{tag}_kernel_stats.csv").read() if ks else "no kernel stats")
