@@ -71,6 +71,10 @@ struct KOut {
     unsigned long long* dbg;   // CRTFX_STAMP diagnostic build only: per-wave phase cycle sums
 };
 
+// internal gate (set by crtfx_set_params, never by callers): the analytic vignette gain lies in [0,1]
+// (0 <= strength <= 1), so clip(x * gain) of an x in [0,1] is the identity and is skipped.
+constexpr uint32_t KF_VIG_UNIT = 1u << 24;
+
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
 constexpr int NB = 8;             // rows per H-pass block / register-blocked V outputs
 constexpr int K1_THREADS = 192;   // 3 wavefronts: wave w owns channel w in the V pass
@@ -162,10 +166,11 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ float grain_normal(uint32_t key0, uint32_t key1, uint32_t idx) {
-    const uint32_t a = lowbias32(idx ^ key0);
-    const uint32_t b = lowbias32((a + 0x9E3779B9U) ^ key1);
-    const float u1 = (float)((a >> 8) + 1u) * 5.9604644775390625e-08f;   // (0, 1]
-    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;          // [0, 1)
+    // one avalanche hash per pixel, split into two 16-bit uniforms (grain is added at ~1/255 of full
+    // scale and then quantised, so 16 bits each is ample; the radius tops out at 4.7 sigma)
+    const uint32_t a = lowbias32(idx ^ key0) ^ key1;
+    const float u1 = (float)((a >> 16) + 1u) * 1.52587890625e-05f;       // (0, 1]
+    const float u2 = (float)(a & 0xFFFFu) * 1.52587890625e-05f;          // [0, 1)
     const float l2 = __builtin_amdgcn_logf(u1);                          // log2
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * l2); // sqrt(-2 ln u1)
     return rad * __builtin_amdgcn_cosf(u2);                              // cos(2 pi u2)
@@ -199,6 +204,8 @@ __device__ __forceinline__ PixMasks load_masks(const KParams& P, const KFrame& F
 // LUT index of ref:250 / :261: clip(trunc(clip(v,0,1) * 1024), 0, 1024).  clip(v) * 1024 lies
 // in [0, 1024] exactly, so the integer clip is the identity and is not re-applied.
 __device__ __forceinline__ int lut_index(float v) { return (int)(clip01(v) * 1024.0f); }
+// the same for a v already known to lie in [0,1] (every stage before the triad ends in a clip)
+__device__ __forceinline__ int lut_index_unit(float v) { return (int)(v * 1024.0f); }
 
 // a7..a11 — from the post-bloom image to the pre-warp image.  The reference's image is float32
 // up to the scanline multiply and float64 from the vignette / flicker multiply on (NumPy
@@ -211,7 +218,7 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
     // a7 — _apply_triad_mask (ref:238-263)
     if (P.flags & CRTFX_F_TRIAD) {
         if (P.flags & CRTFX_F_TRIAD_LUT) {
-            const float l0 = lut_g[lut_index(r)], l1 = lut_g[lut_index(g)], l2 = lut_g[lut_index(b)];
+            const float l0 = lut_g[lut_index_unit(r)], l1 = lut_g[lut_index_unit(g)], l2 = lut_g[lut_index_unit(b)];
             float q0 = l0 * M.m0, q1 = l1 * M.m1, q2 = l2 * M.m2;
             if (P.flags & CRTFX_F_TRIAD_LUMA) {
                 const float yb = (0.2126f * l0 + 0.7152f * l1) + 0.0722f * l2;
@@ -220,7 +227,8 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
                 ratio = fminf(fmaxf(ratio, 0.5f), 2.0f);
                 q0 *= ratio; q1 *= ratio; q2 *= ratio;
             }
-            r = clip01(lut_inv[lut_index(q0)]); g = clip01(lut_inv[lut_index(q1)]); b = clip01(lut_inv[lut_index(q2)]);
+            // LUT entries are linspace(0,1)^(1/gamma): already inside [0,1], the final clip (ref:263) is the identity
+            r = lut_inv[lut_index(q0)]; g = lut_inv[lut_index(q1)]; b = lut_inv[lut_index(q2)];
         } else {
             r = clip01(r * M.m0); g = clip01(g * M.m1); b = clip01(b * M.m2);
         }
@@ -230,7 +238,8 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
     T v0 = (T)r, v1 = (T)g, v2 = (T)b;
     // a9 — vignette (ref:626-628): float64 mask promotes the image
     if (P.flags & CRTFX_F_VIGNETTE) {
-        v0 = (T)clip01((double)v0 * M.vig); v1 = (T)clip01((double)v1 * M.vig); v2 = (T)clip01((double)v2 * M.vig);
+        if (P.flags & KF_VIG_UNIT) { v0 = (T)((double)v0 * M.vig); v1 = (T)((double)v1 * M.vig); v2 = (T)((double)v2 * M.vig); }
+        else { v0 = (T)clip01((double)v0 * M.vig); v1 = (T)clip01((double)v1 * M.vig); v2 = (T)clip01((double)v2 * M.vig); }
     }
     // a10 — flicker (ref:630-633); np.float64 factor
     if (P.flags & CRTFX_F_FLICKER) {
@@ -561,10 +570,14 @@ __host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * r
 // 178 -> 144 us per 4K frame at equal source.  The host picks the instantiation whose SF equals
 // the launch's flags, else the runtime-flag one.
 constexpr uint32_t SF_RUNTIME = 0xFFFFFFFFu;
-constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE;
+constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE | KF_VIG_UNIT;
 
+// The gate-folded build sits right at the 128-VGPR boundary (127..129 depending on small edits):
+// one register over and it drops from 4 to 3 waves per SIMD, i.e. from 4 to 3 resident blocks per
+// CU and a second, partial round of blocks (+22 % time).  It is therefore pinned to 4 waves/SIMD;
+// the runtime-flag build needs ~147 VGPRs and would spill under that cap.
 template <int RT, uint32_t SF>
-__global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KParams Pin, KFrame F, KOut O, int seg_rows) {
+__global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES)) void k_phosphor_rr(KParams Pin, KFrame F, KOut O, int seg_rows) {
     KParams P = Pin;
     if constexpr (SF != SF_RUNTIME) P.flags = SF;
     // declared as float4 so that the 16-byte alignment of the dynamic LDS base is part of the type:
@@ -634,16 +647,20 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
     // Its source column (BORDER_REPLICATE clamp, then the pixelate map) is resolved once here so
     // that the loads issued inside the loop depend on no other vector-memory load: a dependent
     // index load in fetch would put an s_waitcnt vmcnt(0) in front of every item's byte loads.
-    int xsrc[A_ITEMS];
+    uint32_t offr[A_ITEMS], offg[A_ITEMS], offb[A_ITEMS];     // byte offsets of this item's R, G, B inside a frame row
 #pragma unroll
     for (int u = 0; u < A_ITEMS; ++u) {
         const int it = tid + u * RR_THREADS;
         const int i = it - (it / SWP) * SWP;
-        const int x = min(max(x0 - pad + i, 0), W - 1);
-        xsrc[u] = pixelate ? P.xmap[x] : x;
+        int x = min(max(x0 - pad + i, 0), W - 1);
+        if (pixelate) x = P.xmap[x];
+        int xr = x, xb = x;
+        if (P.ab != 0) { xr = wrap(x - P.ab, W); xb = wrap(x + P.ab, W); }      // ref:573-575
+        offr[u] = (uint32_t)xr * 3u; offg[u] = (uint32_t)x * 3u + 1u; offb[u] = (uint32_t)xb * 3u + 2u;
     }
     __syncthreads();                                // ytab / rowtab / lut visible
     RawRGB raw[A_ITEMS];
+    const uint32_t row_bytes = (uint32_t)W * 3u;
     auto prefetch = [&](int hb) {
         const int nrows = min(NB, y_end + R - hb);
 #pragma unroll
@@ -652,7 +669,8 @@ __global__ __launch_bounds__(RR_THREADS, CRTFX_RR_WAVES) void k_phosphor_rr(KPar
             const int j = it / SWP;
             if (j < nrows) {
                 const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
-                raw[u] = fetch_raw_mapped(P, F.in, y, xsrc[u]);
+                const uint32_t ro = (uint32_t)y * row_bytes;          // < 2^32 for any frame the ctx accepts
+                raw[u].r = F.in[ro + offr[u]]; raw[u].g = F.in[ro + offg[u]]; raw[u].b = F.in[ro + offb[u]];
             }
         }
     };
