@@ -96,6 +96,16 @@ typedef struct crtfx_params {
     /* optional device-resident full masks (arbitrary arrays handed to apply_*) */
     const float*  triad_full_dev;    /* H*W*3 float32 */
     const double* vignette_full_dev; /* H*W   float64 */
+    /* cv2.resize(INTER_LINEAR) axes, host tables: per destination index the source index of the first
+     * tap (the second is +1, clamped) and the weight of the second tap, as OpenCV computes them
+     * (fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx; clamped at both ends). */
+    const int32_t* grain_xofs; const float* grain_xw;   /* W: (H//g x W//g) grain plane -> frame   ref:642 */
+    const int32_t* grain_yofs; const float* grain_yw;   /* H */
+    int32_t grain_w, grain_h;                           /* max(1, W//g), max(1, H//g)              ref:638-639 */
+    const int32_t* fbu_xofs; const float* fbu_xw;       /* W: fast bloom, half-res -> frame        ref:607 */
+    const int32_t* fbu_yofs; const float* fbu_yw;       /* H */
+    const int32_t* fbd_xofs; const float* fbd_xw;       /* max(1,W//2): frame -> half-res          ref:606; NULL = exact 2x */
+    const int32_t* fbd_yofs; const float* fbd_yw;       /* max(1,H//2)    decimation (OpenCV's INTER_AREA 2x2 mean) */
 } crtfx_params;
 
 /* Per-frame inputs (everything that changes from frame to frame; ref:1043,1064). */

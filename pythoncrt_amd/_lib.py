@@ -42,6 +42,10 @@ class CrtfxParams(ctypes.Structure):
         ("vig_nx2", _vp), ("vig_ny2", _vp), ("warp_xhat", _vp), ("warp_yhat", _vp),
         ("pix_xmap", _vp), ("pix_ymap", _vp),
         ("triad_full_dev", _vp), ("vignette_full_dev", _vp),
+        ("grain_xofs", _vp), ("grain_xw", _vp), ("grain_yofs", _vp), ("grain_yw", _vp),
+        ("grain_w", ctypes.c_int32), ("grain_h", ctypes.c_int32),
+        ("fbu_xofs", _vp), ("fbu_xw", _vp), ("fbu_yofs", _vp), ("fbu_yw", _vp),
+        ("fbd_xofs", _vp), ("fbd_xw", _vp), ("fbd_yofs", _vp), ("fbd_yw", _vp),
     ]
 
 

@@ -31,6 +31,7 @@ struct crtfx_ctx {
     bool params_set = false;
     KParams kp{};
     DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
+    DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
     float* pre = nullptr;            // H*W*3 float32 pre-warp scratch
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
@@ -99,6 +100,7 @@ KFrame make_kframe(const void* in, const crtfx_frame* f) {
         k.scan_row = f->scan_row_dev;
         k.scan_plane = f->scan_plane_dev;
         k.noise_plane = f->noise_plane_dev;
+        k.overlay_before = (f->overlay_rgba_dev && !f->overlay_after) ? f->overlay_rgba_dev : nullptr;
         k.flicker = f->flicker_factor;
         noise_keys(f->noise_seed, f->frame_index, k.key0, k.key1);
     } else {
@@ -175,7 +177,8 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
     ProfScope ps(c, 0, s);
     // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in
     const bool lean_ok = !c->force_generic && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane &&
-                         ko.blend == CRTFX_BLEND_NONE;
+                         !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
+                         ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after;
     const int R = c->kp.R;
     if (lean_ok && R >= 1 && R <= RR_MAX_RADIUS) {
         const int strips = (c->W + TW - 1) / TW;
@@ -194,22 +197,32 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     const uint32_t fl = c->kp.flags;
     if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev)))
         return fail(c, CRTFX_E_INVALID, "scanlines are on but the frame record carries no scan_row_dev / scan_plane_dev");
-    if (f && (f->overlay_rgba_dev || f->glitch_offs_dev))
-        return fail(c, CRTFX_E_UNSUPPORTED, "text overlay / glitch are not built yet (SURVEY 8f rows 1-2)");
-    if ((fl & CRTFX_F_NOISE) && c->kp.grain > 1)
-        return fail(c, CRTFX_E_UNSUPPORTED, "grain_size > 1 is not built yet (SURVEY 8f row 3)");
     const KFrame kf = make_kframe(in, f);
     const bool warp = (fl & CRTFX_F_WARP) != 0;
-    // two-kernel path: warp on, or a persistence blend behind the bloom kernel (kept lean: the
-    // commit then runs in k_warp's epilogue with an identity map)
-    const bool two = warp || ((fl & CRTFX_F_BLOOM) && ko.blend != CRTFX_BLEND_NONE);
+    const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);
+    const bool ov_after = f && f->overlay_rgba_dev && f->overlay_after;
+    const bool glitch = f && f->glitch_offs_dev;
+    if (glitch && !(f->glitch_cols == 1 || f->glitch_cols == c->W))
+        return fail(c, CRTFX_E_INVALID, "glitch_cols must be 1 or W");
+    if (glitch && (f->glitch_y0 < 0 || f->glitch_y0 >= c->H)) return fail(c, CRTFX_E_INVALID, "glitch_y0 outside the frame");
+    // Two-kernel path (pre-warp float32 image + k_warp): warp on; a glitch gather; or a persistence blend
+    // behind the Gaussian bloom kernel (kept lean; the state is float32 anyway).  An overlay-after with
+    // no warp stays in ONE kernel (the general-purpose build), so that it blends the unrounded image
+    // exactly as ref:653-662 does.
+    const bool two = warp || glitch || (gauss && ko.blend != CRTFX_BLEND_NONE);
+    if (ov_after) ko.overlay_after = f->overlay_rgba_dev;
+    if (glitch) { ko.glitch_offs = f->glitch_offs_dev; ko.glitch_y0 = f->glitch_y0; ko.glitch_cols = f->glitch_cols; }
     KOut k1 = ko;
     if (two) { k1 = KOut{}; k1.pre = c->pre; }
     k1.dbg = c->dbg;
-    if (fl & CRTFX_F_BLOOM) {
+    if (gauss) {
         launch_phosphor(c, kf, k1, s);
     } else {
         ProfScope ps(c, 0, s);
+        if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
+            dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4);
+            hipLaunchKernelGGL(k_half, gh, dim3(256), 0, s, c->kp, kf);
+        }
         dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
         hipLaunchKernelGGL(k_point, grid, dim3(256), 0, s, c->kp, kf, k1);
     }
@@ -265,7 +278,8 @@ int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap}) free_buf(*b);
+    for (DevBuf* b : {&c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
+                      &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
     delete c;
@@ -279,8 +293,10 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     HIP_TRY(c, hipDeviceSynchronize());   // tables may be in use by enqueued work
     const uint32_t fl = p->flags;
     const int H = c->H, W = c->W;
-    if (fl & CRTFX_F_BLOOM_FAST) return fail(c, CRTFX_E_UNSUPPORTED, "fast (half-res bilinear) bloom is not built yet (SURVEY 8f row 3)");
-    if (fl & CRTFX_F_BLOOM) {
+    if ((fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST)) {
+        if (!(p->fbu_xofs && p->fbu_xw && p->fbu_yofs && p->fbu_yw)) return fail(c, CRTFX_E_INVALID, "fast bloom needs the fbu_* upsample axes");
+        if ((p->fbd_xofs != nullptr) != (p->fbd_yofs != nullptr) || (p->fbd_xofs && !(p->fbd_xw && p->fbd_yw))) return fail(c, CRTFX_E_INVALID, "fbd_* axes must be given together");
+    } else if (fl & CRTFX_F_BLOOM) {
         if (p->bloom_radius < 0 || p->bloom_radius > MAX_RADIUS)
             return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d outside [0,%d] (sigma up to ~21)", p->bloom_radius, MAX_RADIUS);
         if (!p->bloom_taps) return fail(c, CRTFX_E_INVALID, "bloom on but bloom_taps NULL");
@@ -293,7 +309,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     if (p->aberration_px < -8 || p->aberration_px > 8) return fail(c, CRTFX_E_INVALID, "aberration_px %d outside [-8,8] (ref:1230)", p->aberration_px);
 
     int rc;
-    const int R = (fl & CRTFX_F_BLOOM) ? p->bloom_radius : 0;
+    const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
+    const int R = ((fl & CRTFX_F_BLOOM) && !fastb) ? p->bloom_radius : 0;
+    const bool grain_up = (fl & CRTFX_F_NOISE) && p->grain_size > 1;
+    if (grain_up && !(p->grain_xofs && p->grain_xw && p->grain_yofs && p->grain_yw && p->grain_w >= 1 && p->grain_h >= 1))
+        return fail(c, CRTFX_E_INVALID, "grain_size > 1 needs the grain_* resize axes");
     if ((rc = upload(c, c->triad_row, p->triad_row, (size_t)W * 3 * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_g, p->lut_g, LUT_N * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_inv, p->lut_inv, LUT_N * sizeof(float)))) return rc;
@@ -303,6 +323,25 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     if ((rc = upload(c, c->yhat, p->warp_yhat, (size_t)H * sizeof(float)))) return rc;
     if ((rc = upload(c, c->xmap, p->pix_xmap, (size_t)W * sizeof(int32_t)))) return rc;
     if ((rc = upload(c, c->ymap, p->pix_ymap, (size_t)H * sizeof(int32_t)))) return rc;
+    const int hw = W / 2 > 1 ? W / 2 : 1, hh = H / 2 > 1 ? H / 2 : 1;
+    if (grain_up) {
+        if ((rc = upload(c, c->gxo, p->grain_xofs, (size_t)W * 4)) || (rc = upload(c, c->gxw, p->grain_xw, (size_t)W * 4)) ||
+            (rc = upload(c, c->gyo, p->grain_yofs, (size_t)H * 4)) || (rc = upload(c, c->gyw, p->grain_yw, (size_t)H * 4))) return rc;
+    }
+    if (fastb) {
+        if ((rc = upload(c, c->uxo, p->fbu_xofs, (size_t)W * 4)) || (rc = upload(c, c->uxw, p->fbu_xw, (size_t)W * 4)) ||
+            (rc = upload(c, c->uyo, p->fbu_yofs, (size_t)H * 4)) || (rc = upload(c, c->uyw, p->fbu_yw, (size_t)H * 4))) return rc;
+        if (p->fbd_xofs) {
+            if ((rc = upload(c, c->dxo, p->fbd_xofs, (size_t)hw * 4)) || (rc = upload(c, c->dxw, p->fbd_xw, (size_t)hw * 4)) ||
+                (rc = upload(c, c->dyo, p->fbd_yofs, (size_t)hh * 4)) || (rc = upload(c, c->dyw, p->fbd_yw, (size_t)hh * 4))) return rc;
+        }
+        const size_t need = (size_t)hw * hh * 3 * sizeof(float);
+        if (c->ds.bytes < need) {
+            free_buf(c->ds);
+            HIP_TRY(c, hipMalloc(&c->ds.p, need));
+            c->ds.bytes = need;
+        }
+    }
 
     KParams k{};
     k.H = H; k.W = W; k.flags = fl & 0xFFFFu; k.ab = p->aberration_px; k.R = R; k.grain = p->grain_size;
@@ -311,7 +350,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
     k.noise_scale = p->noise_scale; k.warp_k = p->warp_k; k.cx = p->warp_cx; k.cy = p->warp_cy;
     k.vig_strength = p->vignette_strength;
-    if (fl & CRTFX_F_BLOOM) std::memcpy(k.taps, p->bloom_taps, (2 * R + 1) * sizeof(float));
+    if ((fl & CRTFX_F_BLOOM) && !fastb) std::memcpy(k.taps, p->bloom_taps, (2 * R + 1) * sizeof(float));
     k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
@@ -319,6 +358,15 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
     k.xmap = (const int*)c->xmap.p; k.ymap = (const int*)c->ymap.p;
+    k.gx_ofs = (const int*)c->gxo.p; k.gx_a = (const float*)c->gxw.p; k.gy_ofs = (const int*)c->gyo.p; k.gy_a = (const float*)c->gyw.p;
+    k.gw = p->grain_w; k.gh = p->grain_h;
+    k.ux_ofs = (const int*)c->uxo.p; k.ux_a = (const float*)c->uxw.p; k.uy_ofs = (const int*)c->uyo.p; k.uy_a = (const float*)c->uyw.p;
+    const bool down_tab = fastb && p->fbd_xofs;
+    k.dx_ofs = down_tab ? (const int*)c->dxo.p : nullptr; k.dx_a = down_tab ? (const float*)c->dxw.p : nullptr;
+    k.dy_ofs = down_tab ? (const int*)c->dyo.p : nullptr; k.dy_a = down_tab ? (const float*)c->dyw.p : nullptr;
+    k.hw = hw; k.hh = hh; k.ds = (float*)c->ds.p;
+    if (fastb && !down_tab && !((W % 2 == 0) && (H % 2 == 0)))
+        return fail(c, CRTFX_E_INVALID, "fast bloom on an odd frame size needs the fbd_* downsample axes");
     if ((fl & CRTFX_F_VIGNETTE) && !p->vignette_full_dev && p->vignette_strength >= 0.0 && p->vignette_strength <= 1.0) k.flags |= KF_VIG_UNIT;
     c->kp = k;
     c->params_set = true;

@@ -50,6 +50,16 @@ struct KParams {
     const float* __restrict__ yhat;
     const int* __restrict__ xmap;
     const int* __restrict__ ymap;
+    // bilinear resize axes (cv2.resize INTER_LINEAR): source index of the first tap and weight of the second
+    const int* __restrict__ gx_ofs; const float* __restrict__ gx_a;     // grain upsample, per output column  (ref:642)
+    const int* __restrict__ gy_ofs; const float* __restrict__ gy_a;     //                 per output row
+    int gw, gh;                                                         // small grain plane size
+    const int* __restrict__ ux_ofs; const float* __restrict__ ux_a;     // fast bloom: half-res -> full upsample (ref:607)
+    const int* __restrict__ uy_ofs; const float* __restrict__ uy_a;
+    const int* __restrict__ dx_ofs; const float* __restrict__ dx_a;     // fast bloom: full -> half downsample when not an exact 2x (ref:606)
+    const int* __restrict__ dy_ofs; const float* __restrict__ dy_a;
+    int hw, hh;                                                         // half-res size (max(1, W//2), max(1, H//2))
+    float* ds;                                                          // half-res thresholded source, hh x hw x 3 float32 (ctx scratch)
 };
 
 struct KFrame {
@@ -57,6 +67,7 @@ struct KFrame {
     const float* __restrict__ scan_row;
     const float* __restrict__ scan_plane;
     const float* __restrict__ noise_plane;
+    const uint8_t* __restrict__ overlay_before;   // H x W x 4 RGBA blended after the grade (ref:588-598), or nullptr
     double flicker;
     uint32_t key0, key1;
 };
@@ -68,6 +79,9 @@ struct KOut {
     float* state;        // persistence state in/out or nullptr
     int blend;           // crtfx_blend
     double p, q;         // persistence, 1 - persistence (double, as python computes them)
+    const uint8_t* __restrict__ overlay_after;   // H x W x 4 RGBA blended after the warp (ref:653-663), or nullptr
+    const int* __restrict__ glitch_offs;         // x offsets of the glitch band (ref:679-682 / 853-855), or nullptr
+    int glitch_y0, glitch_cols;                  // first band row; 1 offset per row or W per row
     unsigned long long* dbg;   // CRTFX_STAMP diagnostic build only: per-wave phase cycle sums
 };
 
@@ -151,6 +165,23 @@ __device__ __forceinline__ void grade(const KParams& P, float& r, float& g, floa
         g = clip01(powf(g, P.inv_gamma));
         b = clip01(powf(b, P.inv_gamma));
     }
+}
+
+// text overlay (ref:588-598 / 653-663): alpha = a/255, rgb = c/255 (float32); img*(1-alpha) + rgb*alpha in the
+// image dtype, the rgb*alpha product in float32 (both factors are float32 arrays), then clip.
+template <typename T>
+__device__ __forceinline__ void overlay_blend(const uint8_t* __restrict__ ov, uint32_t pix, T& v0, T& v1, T& v2) {
+    const uint32_t px = *reinterpret_cast<const uint32_t*>(ov + (size_t)pix * 4);
+    const float a = norm_u8(px >> 24), ia = 1.0f - a;
+    const float c0 = norm_u8(px & 255u) * a, c1 = norm_u8((px >> 8) & 255u) * a, c2 = norm_u8((px >> 16) & 255u) * a;
+    v0 = clip01(v0 * (T)ia + (T)c0); v1 = clip01(v1 * (T)ia + (T)c1); v2 = clip01(v2 * (T)ia + (T)c2);
+}
+
+// a1..a4 (+ overlay-before) of one pixel of the general-purpose kernels; (y, x) in range.
+__device__ __forceinline__ void fetch_graded(const KParams& P, const KFrame& F, int y, int x, float& r, float& g, float& b) {
+    fetch_rgb(P, F.in, y, x, r, g, b);
+    grade(P, r, g, b);
+    if (F.overlay_before) overlay_blend<float>(F.overlay_before, (uint32_t)y * (uint32_t)P.W + (uint32_t)x, r, g, b);
 }
 
 // bloom source (ref:601-604)
@@ -249,8 +280,26 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
     if (P.flags & CRTFX_F_NOISE) {
         const uint32_t idx = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
         float z;
-        if constexpr (PLANES) z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
-        else z = grain_normal(F.key0, F.key1, idx);
+        if constexpr (PLANES) {
+            if (P.grain > 1) {
+                // ref:637-642: N(0,1) drawn at (H//g) x (W//g), cv2.resize INTER_LINEAR up to H x W:
+                // horizontal lerp S[sx]*(1-a) + S[sx+1]*a on both rows, then the vertical one
+                const int sx = P.gx_ofs[x], sy = P.gy_ofs[y];
+                const int sx1 = min(sx + 1, P.gw - 1), sy1 = min(sy + 1, P.gh - 1);
+                const float a1 = P.gx_a[x], a0 = 1.0f - a1, b1 = P.gy_a[y], b0 = 1.0f - b1;
+                const uint32_t i00 = (uint32_t)sy * P.gw + sx, i01 = (uint32_t)sy * P.gw + sx1;
+                const uint32_t i10 = (uint32_t)sy1 * P.gw + sx, i11 = (uint32_t)sy1 * P.gw + sx1;
+                float n00, n01, n10, n11;
+                if (F.noise_plane) { n00 = F.noise_plane[i00]; n01 = F.noise_plane[i01]; n10 = F.noise_plane[i10]; n11 = F.noise_plane[i11]; }
+                else { n00 = grain_normal(F.key0, F.key1, i00); n01 = grain_normal(F.key0, F.key1, i01);
+                       n10 = grain_normal(F.key0, F.key1, i10); n11 = grain_normal(F.key0, F.key1, i11); }
+                z = (n00 * a0 + n01 * a1) * b0 + (n10 * a0 + n11 * a1) * b1;
+            } else {
+                z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
+            }
+        } else {
+            z = grain_normal(F.key0, F.key1, idx);
+        }
         const float n = z * P.noise_scale;
         v0 = clip01(v0 + (T)n); v1 = clip01(v1 + (T)n); v2 = clip01(v2 + (T)n);
     }
@@ -303,7 +352,11 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
 // T is the reference's image dtype at this point (double once promoted).
 // Returns the packed u8 pixel; stores the float outputs itself.
 template <typename T, bool BLEND = true>
-__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, uint32_t pix, T v0, T v1, T v2) {
+__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, uint32_t pix, T v0, T v1, T v2, uint32_t src_pix = 0xFFFFFFFFu) {
+    if constexpr (BLEND) {
+        // text overlay after the effects (ref:653-663); under a glitch gather it is the overlay of the SOURCE column
+        if (O.overlay_after) overlay_blend<T>(O.overlay_after, src_pix == 0xFFFFFFFFu ? pix : src_pix, v0, v1, v2);
+    }
     if (O.out_f32) {
         float* p = O.out_f32 + pix * 3u;
         p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2;
@@ -367,6 +420,43 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
 // k_point — bloom off: the chain is pointwise.  One thread per pixel, 4 rows x 64 px per block.
 // ---------------------------------------------------------------------------------------
 #ifdef CRTFX_MAIN_TU
+// Fast bloom (ref:605-607): ds = cv2.resize(src, (W//2, H//2), INTER_LINEAR); blur = cv2.resize(ds, (W, H), INTER_LINEAR).
+// k_half writes ds (graded + thresholded source at half resolution) into the ctx scratch P.ds:
+//   * exact 2x decimation (W, H even): OpenCV's INTER_AREA fast path, (p00 + p01 + p10 + p11) * 0.25;
+//   * otherwise the generic bilinear taps from the dx/dy axis tables.
+__global__ __launch_bounds__(256) void k_half(KParams P, KFrame F) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= P.hw || j >= P.hh) return;
+    float o[3];
+    if (!P.dx_ofs) {
+        float a[3], b[3], c[3], d[3];
+        fetch_graded(P, F, 2 * j, 2 * i, a[0], a[1], a[2]);
+        fetch_graded(P, F, 2 * j, 2 * i + 1, b[0], b[1], b[2]);
+        fetch_graded(P, F, 2 * j + 1, 2 * i, c[0], c[1], c[2]);
+        fetch_graded(P, F, 2 * j + 1, 2 * i + 1, d[0], d[1], d[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;
+    } else {
+        const int sx = P.dx_ofs[i], sy = P.dy_ofs[j];
+        const int sx1 = min(sx + 1, P.W - 1), sy1 = min(sy + 1, P.H - 1);
+        const float a1 = P.dx_a[i], a0 = 1.0f - a1, b1 = P.dy_a[j], b0 = 1.0f - b1;
+        float a[3], b[3], c[3], d[3];
+        fetch_graded(P, F, sy, sx, a[0], a[1], a[2]);
+        fetch_graded(P, F, sy, sx1, b[0], b[1], b[2]);
+        fetch_graded(P, F, sy1, sx, c[0], c[1], c[2]);
+        fetch_graded(P, F, sy1, sx1, d[0], d[1], d[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            o[k] = (bloom_src(P, a[k]) * a0 + bloom_src(P, b[k]) * a1) * b0 + (bloom_src(P, c[k]) * a0 + bloom_src(P, d[k]) * a1) * b1;
+    }
+    float* q = P.ds + ((size_t)j * P.hw + i) * 3;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+}
+
+// k_point — no Gaussian bloom: the chain is pointwise (plus, for fast bloom, a 2x2 gather from the
+// half-res image k_half left in P.ds).  One thread per pixel, 4 rows x 64 px per block.
 __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     __shared__ float lut[2 * LUT_STRIDE];
     const bool use_lut = (P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT);
@@ -382,7 +472,23 @@ __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     const bool live = x < P.W;
     float r = 0, g = 0, b = 0;
     PixMasks M{};
-    if (live) { M = load_masks(P, F, y, x); fetch_rgb(P, F.in, y, x, r, g, b); grade(P, r, g, b); }
+    if (live) {
+        M = load_masks(P, F, y, x);
+        fetch_graded(P, F, y, x, r, g, b);
+        if (P.flags & CRTFX_F_BLOOM_FAST) {
+            const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
+            const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
+            const float a1 = P.ux_a[x], a0 = 1.0f - a1, b1 = P.uy_a[y], b0 = 1.0f - b1;
+            const float* p00 = P.ds + ((size_t)sy * P.hw + sx) * 3;
+            const float* p01 = P.ds + ((size_t)sy * P.hw + sx1) * 3;
+            const float* p10 = P.ds + ((size_t)sy1 * P.hw + sx) * 3;
+            const float* p11 = P.ds + ((size_t)sy1 * P.hw + sx1) * 3;
+            const float bl0 = (p00[0] * a0 + p01[0] * a1) * b0 + (p10[0] * a0 + p11[0] * a1) * b1;
+            const float bl1 = (p00[1] * a0 + p01[1] * a1) * b0 + (p10[1] * a0 + p11[1] * a1) * b1;
+            const float bl2 = (p00[2] * a0 + p01[2] * a1) * b0 + (p10[2] * a0 + p11[2] * a1) * b1;
+            r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+        }
+    }
     emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
 }
 #endif  // CRTFX_MAIN_TU
@@ -435,8 +541,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
             const int y = min(max(hb + j, 0), H - 1);           // BORDER_REPLICATE
             const int x = min(max(x0 - pad + i, 0), W - 1);
             float r, g, b;
-            fetch_rgb(P, F.in, y, x, r, g, b);
-            grade(P, r, g, b);
+            fetch_graded(P, F, y, x, r, g, b);
             float* s = stg + (j * 3) * SWP + i;
             s[0] = bloom_src(P, r); s[SWP] = bloom_src(P, g); s[2 * SWP] = bloom_src(P, b);
         }
@@ -504,8 +609,7 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
                 PixMasks M{};
                 if (live) {
                     M = load_masks(P, F, y, x);
-                    fetch_rgb(P, F.in, y, x, r, g, b);
-                    grade(P, r, g, b);
+                    fetch_graded(P, F, y, x, r, g, b);
                     // ref:611 img = clip(img + bloom_strength * blur)
                     r = clip01(r + P.bloom_strength * blr[(j * 3 + 0) * TW + lane]);
                     g = clip01(g + P.bloom_strength * blr[(j * 3 + 1) * TW + lane]);
@@ -868,16 +972,25 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
     const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     uint32_t packed = 0;
     if (live) {
+        // a13 glitch (ref:680-685 / 852-858): out[y, x] = post[y, (x + offs) mod W] for the rows of the bottom
+        // band, post being the warped + overlaid image — so everything upstream is evaluated at column xs.
+        int xs = x;
+        if (O.glitch_offs && y >= O.glitch_y0) {
+            const int off = O.glitch_offs[(size_t)(y - O.glitch_y0) * O.glitch_cols + (O.glitch_cols == 1 ? 0 : x)];
+            xs = (x + off) % P.W;
+            if (xs < 0) xs += P.W;
+        }
+        const uint32_t spix = (uint32_t)y * (uint32_t)P.W + (uint32_t)xs;
         if (promotes(P)) {
             double v0, v1, v2;
-            if (identity) { const float* p = pre + pix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-            else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
-            packed = commit_pixel<double>(O, pix, v0, v1, v2);
+            if (identity) { const float* p = pre + spix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            else { int ix, iy, fx, fy; warp_coords(P, y, xs, ix, iy, fx, fy); warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
+            packed = commit_pixel<double>(O, pix, v0, v1, v2, spix);
         } else {
             float v0, v1, v2;
-            if (identity) { const float* p = pre + pix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-            else { int ix, iy, fx, fy; warp_coords(P, y, x, ix, iy, fx, fy); warp_sample<float>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
-            packed = commit_pixel<float>(O, pix, v0, v1, v2);
+            if (identity) { const float* p = pre + spix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
+            else { int ix, iy, fx, fy; warp_coords(P, y, xs, ix, iy, fx, fy); warp_sample<float>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
+            packed = commit_pixel<float>(O, pix, v0, v1, v2, spix);
         }
     }
     if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), packed);

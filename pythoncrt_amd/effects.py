@@ -161,6 +161,12 @@ class Engine:
             flags |= _lib.F_BLOOM
             if s.fast_bloom:
                 flags |= _lib.F_BLOOM_FAST
+                hw, hh = max(1, w // 2), max(1, h // 2)                                  # ref:606
+                keep["fbu"] = tables.resize_linear_axis(w, hw) + tables.resize_linear_axis(h, hh)
+                p.fbu_xofs, p.fbu_xw, p.fbu_yofs, p.fbu_yw = (tables.ptr(a) for a in keep["fbu"])
+                if not (hw * 2 == w and hh * 2 == h):      # not OpenCV's exact-2x INTER_AREA shortcut
+                    keep["fbd"] = tables.resize_linear_axis(hw, w) + tables.resize_linear_axis(hh, h)
+                    p.fbd_xofs, p.fbd_xw, p.fbd_yofs, p.fbd_yw = (tables.ptr(a) for a in keep["fbd"])
             else:
                 k = tables.bloom_ksize(s.bloom_sigma)
                 keep["taps"] = tables.gaussian_taps(k, s.bloom_sigma) if k > 1 else np.ones(1, np.float32)
@@ -208,6 +214,11 @@ class Engine:
         if s.noise_strength > 0.0:
             flags |= _lib.F_NOISE
             p.noise_scale = s.noise_strength / 255.0
+            if s.grain_size and s.grain_size > 1:                                       # ref:637-642
+                gh, gw = max(1, h // int(s.grain_size)), max(1, w // int(s.grain_size))
+                keep["grain"] = tables.resize_linear_axis(w, gw) + tables.resize_linear_axis(h, gh)
+                p.grain_xofs, p.grain_xw, p.grain_yofs, p.grain_yw = (tables.ptr(a) for a in keep["grain"])
+                p.grain_w, p.grain_h = gw, gh
         if s.warp_strength != 0.0:
             flags |= _lib.F_WARP
             keep["xhat"], keep["yhat"], cx, cy = tables.warp_axes(h, w)
@@ -221,9 +232,20 @@ class Engine:
         self.params_key = key
 
     # -- per-frame record ----------------------------------------------------------------
-    def frame_record(self, s: "Settings", scanline_phase_px: float, time_sec: float, noise_seed, frame_index, noise_plane, hold: list):
+    def frame_record(self, s: "Settings", scanline_phase_px: float, time_sec: float, noise_seed, frame_index, noise_plane, hold: list,
+                     overlay=None, overlay_after: bool = True, glitch=None):
         f = _lib.CrtfxFrame()
         h, w = self.h, self.w
+        if overlay is not None:
+            ov = _overlay_tensor(overlay, self.device, h, w)
+            hold.append(ov)
+            f.overlay_rgba_dev = ov.data_ptr()
+            f.overlay_after = 1 if overlay_after else 0
+        if glitch is not None and glitch[1] is not None:
+            y0, offs = glitch
+            t = torch.from_numpy(offs).to(self.device)
+            hold.append(t)
+            f.glitch_offs_dev, f.glitch_y0, f.glitch_cols = t.data_ptr(), int(y0), int(offs.shape[1])
         if s.scanline_strength > 0.0:
             if s.scanline_angle == 0.0 and s.scanline_thickness == 1.0:       # ref:619
                 row = tables.scanline_rows(h, s.scanline_strength, s.scanline_period_px, [scanline_phase_px])[0]
@@ -246,6 +268,23 @@ class Engine:
             self.auto_frame += 1
         f.frame_index = int(frame_index) & 0xFFFFFFFFFFFFFFFF
         return f
+
+
+def _overlay_tensor(ov, device, h, w) -> torch.Tensor:
+    """ref:590-594 — non-uint8 overlays are clipped to 0..255 and cast; a size mismatch would go through
+    PIL's bilinear resize in the reference (cold path, not built)."""
+    if isinstance(ov, torch.Tensor):
+        t = ov if ov.dtype == torch.uint8 else ov.clamp(0, 255).to(torch.uint8)
+    else:
+        a = np.asarray(ov)
+        if a.dtype != np.uint8:
+            a = np.clip(a, 0, 255).astype(np.uint8)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.ndim != 3 or t.shape[2] != 4:
+        raise ValueError(f"text_overlay_rgba must be H x W x 4, got {tuple(t.shape)}")
+    if t.shape[0] != h or t.shape[1] != w:
+        raise NotImplementedError("text_overlay_rgba of a different size (PIL bilinear resize at ref:594/659) is not built")
+    return t.to(device).contiguous()
 
 
 def _check_shape(got, want, name):
@@ -316,13 +355,6 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac):
-    if text_overlay_rgba is not None:
-        raise NotImplementedError("text_overlay_rgba is not built yet (SURVEY 8f row 1)")
-    if glitch_amp_px > 0 and glitch_height_frac > 0.0:
-        raise NotImplementedError("glitch is not built yet (SURVEY 8f row 2)")
-
-
 def apply_crt_effect(
     frame,
     scanline_strength: float,
@@ -364,14 +396,17 @@ def apply_crt_effect(
 ) -> Tuple[object, object]:
     """ref:531-699 — full chain, preview-path persistence (cv2.addWeighted, ref:693) and
     quantise.  Returns (out_u8, img_float); img_float is the next call's `state_prev`."""
-    _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac)
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
     eng = _engine(fr.device, h, w)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []
-    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold)
+    glitch = None
+    if glitch_amp_px > 0 and glitch_height_frac > 0.0:                      # ref:664 — preview variant
+        glitch = tables.glitch_offsets_preview(h, w, scanline_phase_px, glitch_amp_px, glitch_height_frac)
+    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold,
+                           overlay=text_overlay_rgba, overlay_after=text_overlay_after, glitch=glitch)
     out = torch.empty((h, w, 3), dtype=torch.uint8, device=fr.device)
     blend = _lib.BLEND_NONE
     if state_prev is not None and persistence > 0.0:                       # ref:687
@@ -431,14 +466,17 @@ def apply_static_effects(
     noise_plane=None,
 ):
     """ref:702-861 — stateless chain; returns the float image (float32 here)."""
-    _unsupported(text_overlay_rgba, glitch_amp_px, glitch_height_frac)
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
     eng = _engine(fr.device, h, w)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []
-    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold)
+    glitch = None
+    if glitch_amp_px > 0 and glitch_height_frac > 0.0:                      # ref:835 — render variant
+        glitch = tables.glitch_offsets_render(h, w, scanline_phase_px, glitch_amp_px, glitch_height_frac)
+    rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold,
+                           overlay=text_overlay_rgba, overlay_after=text_overlay_after, glitch=glitch)
     img = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)
     with torch.cuda.device(fr.device):
         rc = eng.lib.crtfx_apply_static(eng.ctx, fr.data_ptr(), img.data_ptr(), ctypes.byref(rec), _stream_ptr(fr.device))

@@ -92,8 +92,6 @@ class FramePipeline:
                  noise_seed: int = 0):
         self.device, self.h, self.w, self.rs, self.fps = device, int(h), int(w), settings, float(fps)
         self.noise_seed = int(noise_seed)
-        if settings.glitch_amp_px > 0 and settings.glitch_height_frac > 0.0:
-            raise NotImplementedError("glitch is not built yet (SURVEY 8f row 2)")
         self.engine = Engine(device, h, w)
         self.static = settings.static_settings(self.h, self.w)
         self.engine.set_params(self.static)
@@ -119,6 +117,14 @@ class FramePipeline:
                 for j in range(n):
                     recs[j].scan_plane_dev = planes[j].data_ptr()
         flick = (self.engine.flags & _lib.F_FLICKER) != 0
+        if rs.glitch_amp_px > 0 and rs.glitch_height_frac > 0.0:                                    # ref:835-859, render variant
+            for j, i in enumerate(idx):
+                ph = (int(i) / float(self.fps)) * rs.scanline_speed_px_s
+                y0, offs = tables.glitch_offsets_render(self.h, self.w, ph, rs.glitch_amp_px, rs.glitch_height_frac)
+                if offs is not None:
+                    t = torch.from_numpy(offs).to(self.device)
+                    hold.append(t)
+                    recs[j].glitch_offs_dev, recs[j].glitch_y0, recs[j].glitch_cols = t.data_ptr(), int(y0), int(offs.shape[1])
         for j, i in enumerate(idx):
             recs[j].flicker_factor = tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) if flick else 1.0  # ref:1064
             recs[j].noise_seed = self.noise_seed & 0xFFFFFFFFFFFFFFFF

@@ -150,5 +150,68 @@ def pixelate_maps(h: int, w: int, pixel_size: int):
     return one(w, pixel_size), one(h, pixel_size)
 
 
+def resize_linear_axis(n_dst: int, n_src: int):
+    """One axis of cv2.resize(..., INTER_LINEAR) on float data: for every destination index the source
+    index of the first tap (int32) and the weight of the second tap (float32); the first tap's
+    weight is 1 - w.  fx = (float)((dx + 0.5) * (n_src / n_dst) - 0.5); sx = floor(fx); fx -= sx;
+    clamped to (0, 0) on the left and (n_src - 1, 0) on the right."""
+    scale = n_src / n_dst
+    fx = ((np.arange(n_dst) + 0.5) * scale - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int32)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo = sx < 0
+    fx[lo] = 0.0
+    sx[lo] = 0
+    hi = sx >= n_src - 1
+    fx[hi] = 0.0
+    sx[hi] = n_src - 1
+    return np.ascontiguousarray(sx), np.ascontiguousarray(fx)
+
+
+def glitch_band(h2: int, glitch_height_frac: float):
+    """ref:667 / :838 — first row of the bottom band."""
+    return max(0, min(h2, h2 - int(h2 * glitch_height_frac)))
+
+
+def glitch_offsets_render(h2: int, w2: int, scanline_phase_px: float, glitch_amp_px: int, glitch_height_frac: float):
+    """ref:838-855 — render-path glitch: (y0, int32 offsets (rows, w2)) or (y0, None)."""
+    y0 = glitch_band(h2, glitch_height_frac)
+    if y0 >= h2:
+        return y0, None
+    num_rows = h2 - y0
+    seed = (int(abs(float(scanline_phase_px)) * 2.0) + (w2 << 10) + (h2 << 1)) & 0xFFFFFFFF
+    rng = np.random.default_rng(seed)
+    seg_len = max(8, min(32, w2 // 120 if w2 >= 120 else 8))
+    num_segs = (w2 + seg_len - 1) // seg_len
+    rows_idx = np.arange(num_rows, dtype=np.float32)
+    amp_rows = float(glitch_amp_px) * (1.0 - (rows_idx / max(1.0, float(num_rows))))
+    seg_offsets = rng.standard_normal((num_rows, num_segs)).astype(np.float32) * (amp_rows[:, None] * 0.7)
+    base_rw = rng.standard_normal(num_rows).astype(np.float32)
+    base = np.cumsum(base_rw) * 0.1
+    base = np.clip(base, -amp_rows * 0.4, amp_rows * 0.4)
+    seg_index = (np.arange(w2, dtype=np.int32) // int(seg_len)).astype(np.int32)
+    offs_pp = base[:, None] + seg_offsets[np.arange(num_rows)[:, None], seg_index[None, :]]
+    return y0, np.ascontiguousarray(np.rint(offs_pp).astype(np.int32))
+
+
+def glitch_offsets_preview(h2: int, w2: int, scanline_phase_px: float, glitch_amp_px: int, glitch_height_frac: float):
+    """ref:667-682 — preview-path glitch: (y0, int32 offsets (rows, 1)) or (y0, None)."""
+    y0 = glitch_band(h2, glitch_height_frac)
+    if y0 >= h2:
+        return y0, None
+    num_rows = h2 - y0
+    seed = (int(abs(float(scanline_phase_px)) * 0.05) + (w2 << 10) + (h2 << 1)) & 0xFFFFFFFF
+    rng = np.random.default_rng(seed)
+    rows_idx = np.arange(num_rows, dtype=np.float32)
+    amp_rows = np.asarray(float(glitch_amp_px) * np.exp(-3.0 * (rows_idx / max(1.0, float(num_rows)))), dtype=np.float32)
+    base = rng.normal(loc=0.0, scale=0.5, size=num_rows).astype(np.float32)
+    base = np.clip(base, -1.0, 1.0)
+    jump_mask = rng.random(num_rows).astype(np.float32) < 0.03
+    jump_sign = rng.choice(np.array([-1.0, 1.0], dtype=np.float32), size=num_rows)
+    base = base + jump_mask * jump_sign
+    offs_row = np.clip(base * amp_rows, -amp_rows, amp_rows)
+    return y0, np.ascontiguousarray(np.rint(offs_row).astype(np.int32)[:, None])
+
+
 def ptr(a) -> int:
     return 0 if a is None else a.ctypes.data

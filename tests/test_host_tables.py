@@ -35,7 +35,7 @@ def test_struct_layout_matches_header(lib):
     p = _lib.CrtfxParams()
     p.size = ctypes.sizeof(_lib.CrtfxParams) - 4
     assert lib.crtfx_set_params(None, ctypes.byref(p)) == _lib.E_INVALID
-    assert ctypes.sizeof(_lib.CrtfxParams) == 184 and ctypes.sizeof(_lib.CrtfxFrame) == 80
+    assert ctypes.sizeof(_lib.CrtfxParams) == 288 and ctypes.sizeof(_lib.CrtfxFrame) == 80   # == sizeof in C (gcc on include/crtfx.h)
 
 
 def test_create_without_gpu_fails_cleanly(lib):
@@ -110,3 +110,24 @@ def test_pixelate_maps_match_resize_pair():
         exp = orc.resize(small, (w, h), "nearest")
         xm, ym = tables.pixelate_maps(h, w, p)
         assert np.array_equal(img[ym][:, xm], exp)
+
+
+def test_resize_axis_matches_oracle_resize():
+    rng = np.random.default_rng(1)
+    for n_src, n_dst in [(960, 1920), (540, 1080), (26, 53), (53, 26), (7, 64), (1, 9), (480, 1920)]:
+        src = rng.random((1, n_src), dtype=np.float32)
+        exp = orc.resize(src, (n_dst, 1), "linear")[0]
+        ofs, w1 = tables.resize_linear_axis(n_dst, n_src)
+        s1 = np.minimum(ofs + 1, n_src - 1)
+        got = src[0][ofs] * (np.float32(1.0) - w1) + src[0][s1] * w1
+        if n_src == 2 * n_dst:
+            continue            # exact 2x decimation takes OpenCV's area path in the oracle, not these taps
+        assert np.array_equal(got, exp), (n_src, n_dst)
+
+
+def test_glitch_offsets_match_oracle():
+    for h, w, ph, amp, frac in [(48, 64, 13.0, 9, 0.4), (1080, 1920, 250.0, 40, 0.25), (37, 130, 0.5, 128, 1.0), (20, 20, 3.0, 5, 0.0)]:
+        for a, b in ((tables.glitch_offsets_render, orc.glitch_offsets_render), (tables.glitch_offsets_preview, orc.glitch_offsets_preview)):
+            y0, o = a(h, w, ph, amp, frac)
+            y1, e = b(h, w, ph, amp, frac)
+            assert y0 == y1 and ((o is None and e is None) or np.array_equal(o, e))

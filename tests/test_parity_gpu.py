@@ -299,15 +299,15 @@ def test_tensor_in_tensor_out_and_purity(pc):
 
 def test_errors_are_loud(pc):
     frame = make_frame(48, 64)
-    a = [frame, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, True, 1, 0, 0.0]   # fast_bloom=True
-    with pytest.raises(Exception, match="fast"):
-        pc.apply_static_effects(*a)
+    a = [frame, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0]
     with pytest.raises(ValueError):
         pc.apply_static_effects(frame[:, :, :2], *a[1:])
     with pytest.raises(ValueError):
         pc.apply_static_effects(frame, 0.0, pc.make_triad_mask(10, 10, 0.3), *a[3:])
     with pytest.raises(NotImplementedError):
-        pc.apply_static_effects(*a[:13], False, 1, 5, 0.5)
+        pc.apply_static_effects(*a, text_overlay_rgba=np.zeros((10, 10, 4), np.uint8))       # needs PIL's resize (ref:594)
+    with pytest.raises(Exception, match="radius"):
+        pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                        # sigma 40 -> radius 120 > 64
 
 
 # ---- BASELINE full sizes: size-independent properties ------------------------------------------
@@ -415,3 +415,125 @@ def test_sharded_persistence_pieces_on_gpu():
     local0, out0 = eng.local_scan(frames[:B], first_index=0, clip_start=True)
     torch.cuda.synchronize()
     assert torch.equal(out0, seq_out[:B]) and torch.equal(local0, states[:B])
+
+
+# ---- pixelate, text overlay, glitch, grain size, fast bloom ----------------------------
+
+def static_args(frame, tm, vg, c, glitch=(0, 0.0)):
+    return (frame, c["scanline_strength"], tm, c["triad_gamma"], c["triad_preserve_luma"], c["aberration_px"], c["bloom_sigma"],
+            c["bloom_strength"], c["bloom_threshold"], c["noise_strength"], vg, c["scanline_period_px"], c["scanline_phase_px"],
+            c["fast_bloom"], c["pixel_size"], glitch[0], glitch[1])
+
+
+def both_static(pc, frame, cfg, glitch=(0, 0.0), **kw):
+    c = dict(BASE, **cfg)
+    h, w = frame.shape[:2]
+    tm_g = pc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    tm_o = orc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    vg_g = pc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    vg_o = orc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    return (pc.apply_static_effects(*static_args(frame, tm_g, vg_g, c, glitch), **kw),
+            orc.apply_static_effects(*static_args(frame, tm_o, vg_o, c, glitch), **kw))
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (37, 53), (70, 130)])
+@pytest.mark.parametrize("px", [2, 3, 7])
+def test_pixelate(pc, hw, px):
+    """a3: the INTER_NEAREST down/up pair as composite index maps — integer indexing, bit-exact; also through
+    the bloom kernels (the lean one reads its row map from LDS)."""
+    frame = make_frame(*hw, seed=70)
+    got, exp = both_static(pc, frame, dict(pixel_size=px, aberration_px=1))
+    assert_bit_exact(got, exp)
+    got, exp = both_static(pc, frame, dict(pixel_size=px, aberration_px=-2, bloom_sigma=3.0, bloom_strength=0.25,
+                                           scanline_strength=0.6, scanline_phase_px=1.0, triad=(0.35, 0.5), vignette=0.25))
+    assert_bit_exact(got, exp)
+
+
+def make_overlay(h, w, seed):
+    rng = np.random.default_rng(seed)
+    ov = np.zeros((h, w, 4), np.uint8)
+    ov[h // 4: h // 2, w // 8: w // 2] = rng.integers(0, 256, (h // 2 - h // 4, w // 2 - w // 8, 4), dtype=np.uint8)
+    ov[h // 2:, :, 3] = 255
+    ov[h // 2:, :, :3] = rng.integers(0, 256, (h - h // 2, w, 3), dtype=np.uint8)
+    return ov
+
+
+@pytest.mark.parametrize("after", [False, True])
+@pytest.mark.parametrize("cfg", [dict(scanline_strength=0.6, scanline_phase_px=2.0, aberration_px=1),
+                                 dict(FULL, bloom_sigma=3.0, noise_strength=0.0),
+                                 dict(FULL, bloom_sigma=1.2, noise_strength=0.0, vignette=None)])
+def test_text_overlay(pc, after, cfg):
+    """8f row 1: alpha blend of a supplied RGBA plane before (enters the bloom) or after the effects."""
+    h, w = 70, 130
+    frame = make_frame(h, w, seed=71, kind="grad")
+    ov = make_overlay(h, w, 72)
+    got, exp = both_static(pc, frame, cfg, text_overlay_rgba=ov, text_overlay_after=after)
+    assert_bit_exact(got, exp)
+    gotw, expw = both_static(pc, frame, cfg, text_overlay_rgba=ov, text_overlay_after=after, warp_strength=0.15)
+    assert np.abs(gotw.astype(np.float64) - expw).max() <= 3e-7
+
+
+@pytest.mark.parametrize("warp", [0.0, 0.15])
+def test_glitch_render_and_preview(pc, warp):
+    """8f row 2: both glitch variants (offsets from numpy's PCG64 with the reference's seeds, gather on the GPU)."""
+    h, w = 96, 160
+    frame = make_frame(h, w, seed=73, kind="grad")
+    cfg = dict(scanline_strength=0.6, scanline_phase_px=13.0, aberration_px=1, triad=(0.5, 0.0), bloom_sigma=1.2, bloom_strength=0.25)
+    got, exp = both_static(pc, frame, cfg, glitch=(9, 0.4), warp_strength=warp, text_overlay_rgba=make_overlay(h, w, 74))
+    if warp == 0.0:
+        assert_bit_exact(got, exp)
+    else:
+        assert np.abs(got.astype(np.float64) - exp).max() <= 3e-7
+    c = dict(BASE, **cfg)
+    tm_g, tm_o = pc.make_triad_mask(h, w, 0.5, 0.0), orc.make_triad_mask(h, w, 0.5, 0.0)
+    ug, sg = pc.apply_crt_effect(*crt_args(frame, tm_g, None, 0.0, None, 250.0, c), glitch_amp_px=11, glitch_height_frac=0.5, warp_strength=warp)
+    uo, so = orc.apply_crt_effect(*crt_args(frame, tm_o, None, 0.0, None, 250.0, c), glitch_amp_px=11, glitch_height_frac=0.5, warp_strength=warp)
+    if warp == 0.0:
+        assert np.array_equal(ug, uo) and np.array_equal(sg, so.astype(np.float32))
+    else:
+        assert np.abs(sg.astype(np.float64) - so).max() <= 3e-7 and np.abs(ug.astype(np.int16) - uo.astype(np.int16)).max() <= 1
+
+
+@pytest.mark.parametrize("hw,g", [((48, 64), 2), ((37, 53), 3), ((70, 130), 8), ((20, 30), 64)])
+def test_grain_size(pc, hw, g):
+    """8f row 3: grain drawn at (H//g, W//g) and bilinearly upsampled (cv2.resize INTER_LINEAR)."""
+    h, w = hw
+    frame = make_frame(h, w, seed=75, kind="grad")
+    plane = np.random.default_rng(76).standard_normal((max(1, h // g), max(1, w // g)), dtype=np.float32)
+    cfg = dict(noise_strength=8.0, vignette=0.25, bloom_sigma=1.2, bloom_strength=0.25)
+    got, exp = both_static(pc, frame, cfg, grain_size=g, noise_plane=plane)
+    assert_bit_exact(got, exp)
+    a = pc.apply_static_effects(*static_args(frame, None, None, dict(BASE, noise_strength=8.0)), grain_size=g, noise_seed=3, frame_index=1)
+    b = pc.apply_static_effects(*static_args(frame, None, None, dict(BASE, noise_strength=8.0)), grain_size=g, noise_seed=3, frame_index=1)
+    assert np.array_equal(a, b) and a.std() > 0
+
+
+@pytest.mark.parametrize("hw", [(48, 64), (70, 130), (37, 53), (64, 51), (135, 240)])
+def test_fast_bloom(pc, hw):
+    """8f row 3: the CLI-default bloom — half-res bilinear down (2x2 mean when exact) and up."""
+    frame = make_frame(*hw, seed=77, kind="grad")
+    got, exp = both_static(pc, frame, dict(fast_bloom=True, bloom_sigma=1.2, bloom_strength=0.25, aberration_px=1))
+    assert_bit_exact(got, exp)
+    got, exp = both_static(pc, frame, dict(FULL, fast_bloom=True, bloom_threshold=0.3, noise_strength=0.0, bloom_sigma=0.0))
+    assert_bit_exact(got, exp)
+
+
+def test_cli_default_settings_chain(pc):
+    """The reference CLI's default flag set (ref:1160-1206: pixel_size 2, fast bloom, persistence 0.2, ...)
+    through the frame pipeline against the oracle's in-order render."""
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    h, w, n = 90, 160, 5
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rs = RenderSettings()                 # CLI defaults
+    frames = [make_frame(h, w, seed=80 + i, kind="grad") for i in range(n)]
+    planes = np.random.default_rng(81).standard_normal((n, h, w), dtype=np.float32)
+    pipe = FramePipeline(dev, h, w, rs, fps=24.0, noise_seed=1)
+    out, _ = pipe.run(torch.from_numpy(np.stack(frames)).to(dev), noise_planes=torch.from_numpy(planes).to(dev))
+    params = dict(scanline_strength=rs.scanline_strength, triad_gamma=rs.triad_gamma, triad_preserve_luma=rs.triad_preserve_luma,
+                  aberration_px=rs.aberration_px, bloom_sigma=rs.bloom_sigma, bloom_strength=rs.bloom_strength, noise_strength=rs.noise_strength,
+                  scanline_period_px=rs.scanline_period_px, fast_bloom=rs.fast_bloom, pixel_size=rs.pixel_size)
+    exp, _ = orc.process_frames(frames, params, 24.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength, noise_planes=list(planes))
+    d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert np.array_equal(out[0].cpu().numpy(), exp[0])     # first frame: no blend yet -> bit-exact
