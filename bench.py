@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4])
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 16 at 4K, 32 at 1080p)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -97,9 +97,10 @@ def main():
     from pythoncrt_amd.shard import FrameShard, ShardedRender
     rs, h, w = baseline_config(a.config)
     fps = 30.0
-    B = a.batch or (16 if h >= 2160 else 32)
-    pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234)
-    frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank)
+    B = a.batch or (4 if h >= 4320 else 16 if h >= 2160 else 32)
+    dtype = torch.float16 if a.config == 5 else torch.uint8
+    pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234, dtype=dtype)
+    frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank).to(dtype)
     p = rs.persistence
     shard = FrameShard(world, rank, B)
     engine = GpuShardEngine(pipe, B)
@@ -138,14 +139,14 @@ def main():
     total_frames = B * a.steps * world
     fps_out = total_frames / dt
     px = h * w
-    alg_bytes_frame = px * (6 + (24 if p > 0 else 0))       # u8 in + u8 out (+ f32 state r/w)
+    alg_bytes_frame = px * ((12 if a.config == 5 else 6) + (24 if p > 0 else 0))   # u8 (fp16) in + out (+ f32 state r/w)
     res = {
         "metric": "4K frames/sec (whole node) + achieved HBM GB/s as % of MI355X peak" if a.config == 3 else f"{h}p frames/sec (whole node)",
         "value": round(fps_out, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{a.config - 1}]: {w}x{h} full chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
-                               f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, u8 in/out",
+                               f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, {'fp16' if a.config == 5 else 'u8'} in/out",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
     }
     if rank == 0:
@@ -167,7 +168,7 @@ def main():
                 "algorithmic_bytes_per_frame": alg_bytes_frame, "dominant_kernel": dom[0],
                 "kernels_ms": {k: round(v[0], 4) for k, v in kt.items()}, "launches": {k: v[1] for k, v in kt.items()},
             }
-        if world == 1 and a.cpu_frames != 0:
+        if world == 1 and a.cpu_frames != 0 and a.config != 5:
             n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work
             v, secs = cpu_baseline(rs, h, w, fps, n_cpu)
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",

@@ -135,17 +135,17 @@ struct ProfScope {
     ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0);
 
 // Rows per k_phosphor block.  Every block of the grid should be resident at once (a second,
 // partial round of blocks costs a whole extra block lifetime), so the grid is sized to the
 // number of block slots: blocks-per-CU (LDS-limited) x 256 CUs.  Measured (4K, R=9): 128 rows x 1020
 // blocks 103 us; 184 rows x 720 blocks 118 us; 96 rows x 1380 blocks 119 us.  1080p, R=4: 32 rows x 1020
 // blocks 29 us against 34 us at 64 rows — filling the slots beats the extra halo rows; floor 24 rows.
-int pick_seg_rows(int H, int W, int R) {
+int pick_seg_rows(int H, int W, int R, int pix = 0) {
     if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) return ((v + NB - 1) / NB) * NB; }   // tuning experiments
     const int strips = (W + TW - 1) / TW;
-    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false);
+    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
     int bpc = (int)(163840 / lds);
     if (bpc > 4) bpc = 4;      // 4 waves per SIMD is what the register budget allows
     if (bpc < 1) bpc = 1;
@@ -158,8 +158,8 @@ int pick_seg_rows(int H, int W, int R) {
     return seg > hmax ? hmax : seg;
 }
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate) {
-    return ((size_t)rr_lds_fixed_floats(R) + (size_t)seg_rows * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
+    return ((size_t)rr_lds_fixed_floats(R, pix) + (size_t)seg_rows * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -180,11 +180,15 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
                          !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
                          ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after;
     const int R = c->kp.R;
-    if (lean_ok && R >= 1 && R <= RR_MAX_RADIUS) {
+    // half frames have a lean build only for the full-chain gate set; anything else takes the generic kernel
+    const bool f16_ok = c->pix_fmt != CRTFX_PIX_F16 || ((c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags);
+    if (lean_ok && f16_ok && R >= 1 && R <= RR_MAX_RADIUS) {
         const int strips = (c->W + TW - 1) / TW;
         const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
-        const int variant = ((c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags) ? 1 : 0;
-        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs), phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0), s, variant);
+        const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+        const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
+        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs),
+                 phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt), s, variant);
     } else {
         launch_generic(c, kf, ko, s);
     }
@@ -192,6 +196,7 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
 
 // The whole chain for one frame.  ko describes the FINAL outputs.
 int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipStream_t s) {
+    ko.pix = c->pix_fmt;
     if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
     if (!in) return fail(c, CRTFX_E_INVALID, "frame pointer is NULL");
     const uint32_t fl = c->kp.flags;
@@ -255,7 +260,7 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     if (!out_ctx) return CRTFX_E_INVALID;
     *out_ctx = nullptr;
     if (height <= 0 || width <= 0 || height > 32767 || width > 32767) return CRTFX_E_INVALID;
-    if (pix_fmt != CRTFX_PIX_U8) return CRTFX_E_UNSUPPORTED;   // CRTFX_PIX_F16: BASELINE config 5, not built yet
+    if (pix_fmt != CRTFX_PIX_U8 && pix_fmt != CRTFX_PIX_F16) return CRTFX_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CRTFX_E_HIP;
     if (hipSetDevice(device) != hipSuccess) return CRTFX_E_HIP;
@@ -263,7 +268,7 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     if (!c) return CRTFX_E_NOMEM;
     c->device = device; c->H = height; c->W = width; c->pix_fmt = pix_fmt;
     if (hipMalloc((void**)&c->pre, (size_t)height * width * 3 * sizeof(float)) != hipSuccess) { delete c; return CRTFX_E_NOMEM; }
-    c->seg_rows = pick_seg_rows(height, width, 9);
+    c->seg_rows = pick_seg_rows(height, width, 9, pix_fmt);
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
@@ -344,7 +349,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     }
 
     KParams k{};
-    k.H = H; k.W = W; k.flags = fl & 0xFFFFu; k.ab = p->aberration_px; k.R = R; k.grain = p->grain_size;
+    k.H = H; k.W = W; k.pix = c->pix_fmt; k.flags = fl & 0xFFFFu; k.ab = p->aberration_px; k.R = R; k.grain = p->grain_size;
     k.sat = p->saturation; k.r_gain = p->r_gain; k.b_gain = p->b_gain;
     k.contrast = p->contrast; k.brightness = p->brightness; k.inv_gamma = p->inv_gamma;
     k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
@@ -370,7 +375,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     if ((fl & CRTFX_F_VIGNETTE) && !p->vignette_full_dev && p->vignette_strength >= 0.0 && p->vignette_strength <= 1.0) k.flags |= KF_VIG_UNIT;
     c->kp = k;
     c->params_set = true;
-    c->seg_rows = pick_seg_rows(H, W, R);
+    c->seg_rows = pick_seg_rows(H, W, R, c->pix_fmt);
 
     if (fl & CRTFX_F_BLOOM) {
         const size_t lds = phosphor_lds_bytes(R);
@@ -416,6 +421,7 @@ int crtfx_blend_quantise(crtfx_ctx* c, const float* static_dev, float* state_ino
     ko.state = state_inout_dev;
     ko.blend = blend;
     ko.p = persistence; ko.q = 1.0 - persistence;
+    ko.pix = c->pix_fmt;
     ProfScope ps(c, 1, (hipStream_t)stream);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
     hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, static_dev, (const float*)nullptr, 0.0, ko, 0);
@@ -431,6 +437,7 @@ int crtfx_halo_correct_quantise(crtfx_ctx* c, const float* local_dev, const floa
     ko.out_u8 = static_cast<uint8_t*>(out_pix_dev);
     ko.state = state_out_dev;
     ko.blend = CRTFX_BLEND_NONE;
+    ko.pix = c->pix_fmt;
     ProfScope ps(c, 1, (hipStream_t)stream);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
     hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, local_dev, carry_in_dev, coeff, ko, 1);

@@ -6,7 +6,7 @@
 namespace crtfx {
 
 // One per radius, each in its own translation unit (crtfx_rr.hip compiled with -DRR_R=n) so the
-// twelve sets of instantiations build in parallel.  variant: 1 = SF_FULL gates folded, 0 = runtime.
+// twelve sets of instantiations build in parallel.  variant: 0 = runtime gates (uint8), 1 = SF_FULL gates folded (uint8), 2 = SF_FULL + half frames.
 using rr_launch_fn = void (*)(const KParams&, const KFrame&, const KOut&, int seg_rows, dim3 grid, size_t lds, hipStream_t, int variant);
 
 #define CRTFX_RR_DECL(r) void rr_launch_##r(const KParams&, const KFrame&, const KOut&, int, dim3, size_t, hipStream_t, int);

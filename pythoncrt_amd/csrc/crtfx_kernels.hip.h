@@ -29,6 +29,7 @@ constexpr int MAX_TAPS = 2 * MAX_RADIUS + 1;
 // ---------------------------------------------------------------------------------------
 struct KParams {
     int H, W;
+    int pix;             // crtfx_pixfmt of the frames: 0 = uint8, 1 = IEEE half on the same 0..255 scale
     uint32_t flags;
     int ab;
     int R;
@@ -77,6 +78,7 @@ struct KOut {
     float* out_f32;      // final static float image or nullptr
     uint8_t* out_u8;     // quantised frame or nullptr
     float* state;        // persistence state in/out or nullptr
+    int pix;             // crtfx_pixfmt of out_u8 (the quantised frame): uint8, or half = |x*255| unrounded
     int blend;           // crtfx_blend
     double p, q;         // persistence, 1 - persistence (double, as python computes them)
     const uint8_t* __restrict__ overlay_after;   // H x W x 4 RGBA blended after the warp (ref:653-663), or nullptr
@@ -118,29 +120,36 @@ __device__ __forceinline__ int wrap(int x, int W) {
 
 // a1+a2(+a3): one RGB sample of the aberrated (and pixelated) float image; (y, x) in range.
 // ref:569-584 — R'[x] = R[(x-d) mod W], B'[x] = B[(x+d) mod W]; pixelate = index maps.
-struct RawRGB { uint32_t r, g, b; };
-// (y, x) already mapped through the pixelate index maps (or pixelate off): no dependent loads.
-__device__ __forceinline__ RawRGB fetch_raw_mapped(const KParams& P, const uint8_t* __restrict__ in, int y, int x) {
-    const uint8_t* row = in + (size_t)y * P.W * 3;
-    int xr = x, xb = x;
-    if (P.ab != 0) { xr = wrap(x - P.ab, P.W); xb = wrap(x + P.ab, P.W); }
-    RawRGB v;
-    v.r = row[xr * 3 + 0]; v.g = row[x * 3 + 1]; v.b = row[xb * 3 + 2];
+struct RawRGB { uint32_t r, g, b; };   // the three stored samples of a pixel: bytes, or half bit patterns
+
+// a1 for either pixel format: uint8 -> u/255 (norm_u8); half -> float(h)/255 with a true division
+// (ref:569 `frame.astype(np.float32) / 255.0` applied to a float16 frame array).
+__device__ __forceinline__ float norm_px(int pix, uint32_t s) {
+    if (pix == CRTFX_PIX_F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)s) / 255.0f;
+    return norm_u8(s);
+}
+__device__ __forceinline__ RawRGB load_raw(int pix, const uint8_t* __restrict__ in, uint32_t er, uint32_t eg, uint32_t eb) {
+    RawRGB v;      // er/eg/eb: ELEMENT offsets of the three samples from the frame base
+    if (pix == CRTFX_PIX_F16) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(in);
+        v.r = p[er]; v.g = p[eg]; v.b = p[eb];
+    } else {
+        v.r = in[er]; v.g = in[eg]; v.b = in[eb];
+    }
     return v;
 }
+// (y, x) already mapped through the pixelate index maps (or pixelate off): no dependent loads.
 __device__ __forceinline__ RawRGB fetch_raw(const KParams& P, const uint8_t* __restrict__ in, int y, int x) {
     if (P.flags & CRTFX_F_PIXELATE) { x = P.xmap[x]; y = P.ymap[y]; }
-    const uint8_t* row = in + (size_t)y * P.W * 3;
+    const uint32_t row = (uint32_t)y * (uint32_t)P.W * 3u;
     int xr = x, xb = x;
     if (P.ab != 0) { xr = wrap(x - P.ab, P.W); xb = wrap(x + P.ab, P.W); }
-    RawRGB v;
-    v.r = row[xr * 3 + 0]; v.g = row[x * 3 + 1]; v.b = row[xb * 3 + 2];
-    return v;
+    return load_raw(P.pix, in, row + (uint32_t)xr * 3u, row + (uint32_t)x * 3u + 1u, row + (uint32_t)xb * 3u + 2u);
 }
 __device__ __forceinline__ void fetch_rgb(const KParams& P, const uint8_t* __restrict__ in, int y, int x,
                                           float& r, float& g, float& b) {
     const RawRGB v = fetch_raw(P, in, y, x);
-    r = norm_u8(v.r); g = norm_u8(v.g); b = norm_u8(v.b);
+    r = norm_px(P.pix, v.r); g = norm_px(P.pix, v.g); b = norm_px(P.pix, v.b);
 }
 
 // a4 — apply_color_adjustments (ref:279-305), float32 throughout.
@@ -317,6 +326,11 @@ __device__ __forceinline__ uint32_t quant_u8(float v) {
     return (uint32_t)min(max(r, 0), 255);
 }
 
+// a15 for half frames: |x*255| narrowed to half (convertScaleAbs without the integer rounding)
+__device__ __forceinline__ uint32_t quant_f16(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)fabsf(v * 255.0f)); }   // RNE narrowing
+
+struct PackedPix { uint32_t lo, hi; };   // uint8: lo = r | g<<8 | b<<16.  half: lo = r | g<<16, hi = b.
+
 // Store 64 consecutive pixels' RGB bytes of one row from one wavefront.  Lane l holds pixel
 // (x0 + l) packed as r | g<<8 | b<<16.  When the row segment is dword-aligned the wavefront
 // re-packs through lane shuffles and lanes 0..47 store one dword each (192 contiguous bytes);
@@ -348,11 +362,23 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
     }
 }
 
+// One row segment of half pixels: each lane stores its own three halves (6 bytes, 2-byte aligned).
+__device__ __forceinline__ void store_row_f16(uint8_t* __restrict__ out, size_t row_px0, int lane, int valid_px, PackedPix pk) {
+    if (lane < valid_px) {
+        uint16_t* p = reinterpret_cast<uint16_t*>(out) + (row_px0 + (size_t)lane) * 3;
+        p[0] = (uint16_t)pk.lo; p[1] = (uint16_t)(pk.lo >> 16); p[2] = (uint16_t)pk.hi;
+    }
+}
+__device__ __forceinline__ void store_row_pix(const KOut& O, size_t row_px0, int lane, int valid_px, PackedPix pk) {
+    if (O.pix == CRTFX_PIX_F16) store_row_f16(O.out_u8, row_px0, lane, valid_px, pk);
+    else store_row_u8(O.out_u8, row_px0 * 3, lane, valid_px, pk.lo);
+}
+
 // a14 + a15 — commit epilogue shared by every kernel that produces final pixels.
 // T is the reference's image dtype at this point (double once promoted).
 // Returns the packed u8 pixel; stores the float outputs itself.
 template <typename T, bool BLEND = true>
-__device__ __forceinline__ uint32_t commit_pixel(const KOut& O, uint32_t pix, T v0, T v1, T v2, uint32_t src_pix = 0xFFFFFFFFu) {
+__device__ __forceinline__ PackedPix commit_pixel(const KOut& O, uint32_t pix, T v0, T v1, T v2, uint32_t src_pix = 0xFFFFFFFFu) {
     if constexpr (BLEND) {
         // text overlay after the effects (ref:653-663); under a glitch gather it is the overlay of the SOURCE column
         if (O.overlay_after) overlay_blend<T>(O.overlay_after, src_pix == 0xFFFFFFFFu ? pix : src_pix, v0, v1, v2);
@@ -381,7 +407,10 @@ __device__ __forceinline__ uint32_t commit_pixel(const KOut& O, uint32_t pix, T 
         float* s = O.state + pix * 3u;
         s[0] = f0; s[1] = f1; s[2] = f2;
     }
-    return quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16);
+    PackedPix pk;
+    if (O.pix == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+    else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+    return pk;
 }
 
 // One finished pre-warp pixel: either park it for k_warp or commit it.
@@ -392,7 +421,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
                                            const float* lut_g, const float* lut_inv) {
     const int x = x0 + lane;
     const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-    uint32_t packed = 0;
+    PackedPix packed{0, 0};
     if (promotes(P)) {
         double v0 = 0, v1 = 0, v2 = 0;
         if (live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
@@ -410,10 +439,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
         }
         if (live) packed = commit_pixel<float, !LEAN>(O, pix, v0, v1, v2);
     }
-    if (O.out_u8) {
-        const int valid = min(64, P.W - x0);
-        store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, valid, packed);
-    }
+    if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), packed);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -666,7 +692,7 @@ __host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
 __host__ __device__ constexpr int rr_sws(int R) { return (rr_swp(R) + 63) & ~63; }
 __host__ __device__ constexpr int rr_cring(int R) { return R + 2 * NB; }   // exact: LDS is what caps blocks per CU
 // LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
-__host__ __device__ constexpr int rr_lds_fixed_floats(int R) { return NB * 3 * rr_sws(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW; }
+__host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix) { return NB * 3 * rr_sws(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW * (pix ? 2 : 1); }
 
 // SF: the stage gates (crtfx_params.flags without CRTFX_F_WARP, which k_phosphor never reads) as a
 // compile-time constant, or SF_RUNTIME.  With the gates folded the dead stages, their parameters
@@ -680,10 +706,14 @@ constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT |
 // one register over and it drops from 4 to 3 waves per SIMD, i.e. from 4 to 3 resident blocks per
 // CU and a second, partial round of blocks (+22 % time).  It is therefore pinned to 4 waves/SIMD;
 // the runtime-flag build needs ~147 VGPRs and would spill under that cap.
-template <int RT, uint32_t SF>
+// PIX: pixel format of the frames (folded like the gates); half frames park 2 dwords per centre pixel.
+template <int RT, uint32_t SF, int PIX = 0>
 __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES)) void k_phosphor_rr(KParams Pin, KFrame F, KOut O, int seg_rows) {
     KParams P = Pin;
     if constexpr (SF != SF_RUNTIME) P.flags = SF;
+    P.pix = PIX;
+    O.pix = PIX;
+    constexpr int CRW = PIX ? 2 : 1;            // dwords per parked centre pixel
     // declared as float4 so that the 16-byte alignment of the dynamic LDS base is part of the type:
     // with a float[] base hipcc splits every 16-byte LDS access into ds_read2_b32/_b64 pairs, which
     // at a 16-byte lane stride are 4-way / 2-way bank conflicts (ds_read_b128 is conflict-free).
@@ -702,7 +732,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     float* hrow = stg + NB * 3 * SWS;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
     uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // [CR][TW] packed centre pixels
-    uint32_t* rowtab = cring + CR * TW;                                    // [seg_rows][3]: scan gain bits, ny2 lo, ny2 hi
+    uint32_t* rowtab = cring + CR * TW * CRW;                              // [seg_rows][3]: scan gain bits, ny2 lo, ny2 hi
     int* ytab = reinterpret_cast<int*>(rowtab + seg_rows * 3);             // [seg_rows + 2R]: source row of halo row (pixelate)
 
     const int tid = threadIdx.x;
@@ -751,7 +781,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     // Its source column (BORDER_REPLICATE clamp, then the pixelate map) is resolved once here so
     // that the loads issued inside the loop depend on no other vector-memory load: a dependent
     // index load in fetch would put an s_waitcnt vmcnt(0) in front of every item's byte loads.
-    uint32_t offr[A_ITEMS], offg[A_ITEMS], offb[A_ITEMS];     // byte offsets of this item's R, G, B inside a frame row
+    uint32_t offr[A_ITEMS], offg[A_ITEMS], offb[A_ITEMS];     // element offsets of this item's R, G, B inside a frame row
 #pragma unroll
     for (int u = 0; u < A_ITEMS; ++u) {
         const int it = tid + u * RR_THREADS;
@@ -764,7 +794,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     }
     __syncthreads();                                // ytab / rowtab / lut visible
     RawRGB raw[A_ITEMS];
-    const uint32_t row_bytes = (uint32_t)W * 3u;
+    const uint32_t row_bytes = (uint32_t)W * 3u;           // elements per frame row
     auto prefetch = [&](int hb) {
         const int nrows = min(NB, y_end + R - hb);
 #pragma unroll
@@ -774,7 +804,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             if (j < nrows) {
                 const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
                 const uint32_t ro = (uint32_t)y * row_bytes;          // < 2^32 for any frame the ctx accepts
-                raw[u].r = F.in[ro + offr[u]]; raw[u].g = F.in[ro + offg[u]]; raw[u].b = F.in[ro + offb[u]];
+                raw[u] = load_raw(PIX, F.in, ro + offr[u], ro + offg[u], ro + offb[u]);
             }
         }
     };
@@ -789,11 +819,14 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
                 float r = 0, g = 0, b = 0;
                 PixMasks M{cm0, cm1, cm2, 1.0f, 1.0};
                 if (xin) {
-                    const uint32_t pk = cring[((y - (y_begin - R)) % CR) * TW + lane];
+                    const uint32_t* cp = cring + (((y - (y_begin - R)) % CR) * TW + lane) * CRW;
+                    uint32_t s0, s1, s2;
+                    if constexpr (PIX) { const uint32_t lo = cp[0]; s0 = lo & 0xFFFFu; s1 = lo >> 16; s2 = cp[1]; }
+                    else { const uint32_t pk = cp[0]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
                     const uint32_t* rt = rowtab + (y - y_begin) * 3;
                     M.sl = __uint_as_float(rt[0]);
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
-                    r = norm_u8(pk & 255u); g = norm_u8((pk >> 8) & 255u); b = norm_u8((pk >> 16) & 255u);
+                    r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
                     grade(P, r, g, b);
                     r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
                     g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
@@ -836,9 +869,12 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             const int it = tid + u * RR_THREADS;
             const int j = it / SWP, i = it - j * SWP;
             if (j < nrows) {
-                if (i >= pad && i < pad + TW)       // centre column: park the packed bytes for C2
-                    cring[((hb + j - (y_begin - R)) % CR) * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
-                float r = norm_u8(raw[u].r), g = norm_u8(raw[u].g), b = norm_u8(raw[u].b);
+                if (i >= pad && i < pad + TW) {     // centre column: park the packed samples for C2
+                    uint32_t* cp = cring + (((hb + j - (y_begin - R)) % CR) * TW + (i - pad)) * CRW;
+                    if constexpr (PIX) { cp[0] = raw[u].r | (raw[u].g << 16); cp[1] = raw[u].b; }
+                    else cp[0] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
+                }
+                float r = norm_px(PIX, raw[u].r), g = norm_px(PIX, raw[u].g), b = norm_px(PIX, raw[u].b);
                 grade(P, r, g, b);
                 float* s = stg + (j * 3) * SWS + i;
                 s[0] = bloom_src(P, r); s[SWS] = bloom_src(P, g); s[2 * SWS] = bloom_src(P, b);
@@ -951,14 +987,13 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
     const F3 B = *reinterpret_cast<const F3*>(pre + (rowa + (uint32_t)xb) * 3u);
     const F3 C = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xa) * 3u);
     const F3 D = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xb) * 3u);
-    const bool ka = xin0 && yin0, kb = xin1 && yin0, kc = xin0 && yin1, kd = xin1 && yin1;
-    const T a0 = ka ? (T)A.x : (T)0, a1 = ka ? (T)A.y : (T)0, a2 = ka ? (T)A.z : (T)0;
-    const T b0 = kb ? (T)B.x : (T)0, b1 = kb ? (T)B.y : (T)0, b2 = kb ? (T)B.z : (T)0;
-    const T c0 = kc ? (T)C.x : (T)0, c1 = kc ? (T)C.y : (T)0, c2 = kc ? (T)C.z : (T)0;
-    const T d0 = kd ? (T)D.x : (T)0, d1 = kd ? (T)D.y : (T)0, d2 = kd ? (T)D.z : (T)0;
-    o0 = ((a0 * (T)w00 + b0 * (T)w01) + c0 * (T)w10) + d0 * (T)w11;
-    o1 = ((a1 * (T)w00 + b1 * (T)w01) + c1 * (T)w10) + d1 * (T)w11;
-    o2 = ((a2 * (T)w00 + b2 * (T)w01) + c2 * (T)w10) + d2 * (T)w11;
+    // a tap outside the image contributes borderValue 0: 0 * w == v * 0 for finite v, so the tap's WEIGHT is
+    // zeroed (4 selects) instead of its three channel values (12)
+    const float u00 = (xin0 && yin0) ? w00 : 0.0f, u01 = (xin1 && yin0) ? w01 : 0.0f;
+    const float u10 = (xin0 && yin1) ? w10 : 0.0f, u11 = (xin1 && yin1) ? w11 : 0.0f;
+    o0 = (((T)A.x * (T)u00 + (T)B.x * (T)u01) + (T)C.x * (T)u10) + (T)D.x * (T)u11;
+    o1 = (((T)A.y * (T)u00 + (T)B.y * (T)u01) + (T)C.y * (T)u10) + (T)D.y * (T)u11;
+    o2 = (((T)A.z * (T)u00 + (T)B.z * (T)u01) + (T)C.z * (T)u10) + (T)D.z * (T)u11;
 }
 
 #ifdef CRTFX_MAIN_TU
@@ -970,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
     const int x = x0 + lane;
     const bool live = x < P.W;
     const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-    uint32_t packed = 0;
+    PackedPix packed{0, 0};
     if (live) {
         // a13 glitch (ref:680-685 / 852-858): out[y, x] = post[y, (x + offs) mod W] for the rows of the bottom
         // band, post being the warped + overlaid image — so everything upstream is evaluated at column xs.
@@ -984,7 +1019,14 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
         if (promotes(P)) {
             double v0, v1, v2;
             if (identity) { const float* p = pre + spix * 3u; v0 = p[0]; v1 = p[1]; v2 = p[2]; }
-            else { int ix, iy, fx, fy; warp_coords(P, y, xs, ix, iy, fx, fy); warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2); }
+            else {
+                int ix, iy, fx, fy; warp_coords(P, y, xs, ix, iy, fx, fy);
+#ifdef CRTFX_WARP_F32
+                float f0, f1, f2; warp_sample<float>(P, pre, ix, iy, fx, fy, f0, f1, f2); v0 = f0; v1 = f1; v2 = f2;
+#else
+                warp_sample<double>(P, pre, ix, iy, fx, fy, v0, v1, v2);
+#endif
+            }
             packed = commit_pixel<double>(O, pix, v0, v1, v2, spix);
         } else {
             float v0, v1, v2;
@@ -993,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict
             packed = commit_pixel<float>(O, pix, v0, v1, v2, spix);
         }
     }
-    if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), packed);
+    if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), packed);
 }
 #endif  // CRTFX_MAIN_TU
 
@@ -1030,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __res
     const int x = x0 + lane;
     const bool live = x < W;
     const uint32_t pix = (uint32_t)y * (uint32_t)W + (uint32_t)x;
-    uint32_t packed = 0;
+    PackedPix packed{0, 0};
     if (live) {
         const float* p = src + pix * 3u;
         if (mode == 1) {
@@ -1042,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __res
             packed = commit_pixel<float>(O, pix, p[0], p[1], p[2]);
         }
     }
-    if (O.out_u8) store_row_u8(O.out_u8, ((size_t)y * W + x0) * 3, lane, min(64, W - x0), packed);
+    if (O.out_u8) store_row_pix(O, (size_t)y * W + x0, lane, min(64, W - x0), packed);
 }
 #endif  // CRTFX_MAIN_TU
 

@@ -13,10 +13,12 @@ namespace crtfx {
 
 void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KFrame& kf, const KOut& ko, int seg_rows, dim3 grid, size_t lds,
                                  hipStream_t s, int variant) {
-    if (variant == 1)
-        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_FULL>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
+    if (variant == 2)       // half frames, full-chain gates
+        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
+    else if (variant == 1)
+        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
     else
-        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_RUNTIME>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
+        hipLaunchKernelGGL((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, kp, kf, ko, seg_rows);
 }
 
 }  // namespace crtfx

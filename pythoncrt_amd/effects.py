@@ -102,14 +102,15 @@ def _fresh_seed() -> int:
 class Engine:
     """Owns a crtfx ctx, the host tables and the device-side per-frame scratch tensors."""
 
-    def __init__(self, device: torch.device, h: int, w: int):
+    def __init__(self, device: torch.device, h: int, w: int, pix_fmt: int = _lib.PIX_U8):
+        self.pix_fmt = pix_fmt
         if device.type != "cuda":
             raise RuntimeError(f"pythoncrt_amd needs a ROCm device, got {device}")
         self.lib = _lib.load()
         self.device, self.h, self.w = device, int(h), int(w)
         ctx = ctypes.c_void_p()
         rc = self.lib.crtfx_create(device.index if device.index is not None else torch.cuda.current_device(),
-                                   self.h, self.w, _lib.PIX_U8, ctypes.byref(ctx))
+                                   self.h, self.w, pix_fmt, ctypes.byref(ctx))
         if rc != _lib.OK:
             raise _lib.CrtfxError(rc, f"crtfx_create({device}, {h}, {w}) failed")
         self.ctx = ctx
@@ -302,14 +303,14 @@ def _as_device_tensor(a, device, dtype, shape, name) -> torch.Tensor:
     return t
 
 
-def _engine(device: torch.device, h: int, w: int) -> Engine:
+def _engine(device: torch.device, h: int, w: int, pix_fmt: int = _lib.PIX_U8) -> Engine:
     cache = getattr(_tls, "engines", None)
     if cache is None:
         cache = _tls.engines = {}
-    k = (device.index, h, w)
+    k = (device.index, h, w, pix_fmt)
     e = cache.get(k)
     if e is None:
-        e = cache[k] = Engine(device, h, w)
+        e = cache[k] = Engine(device, h, w, pix_fmt)
     return e
 
 
@@ -335,16 +336,17 @@ class Settings:
 
 
 def _frame_to_device(frame):
-    """-> (uint8 tensor H x W x 3 on a ROCm device, was_numpy)."""
+    """-> (uint8 or float16 tensor H x W x 3 on a ROCm device, was_numpy).  A float16 frame is the
+    reference's frame array held as half (same 0..255 scale, ref:569); its output frame is half too."""
     if isinstance(frame, torch.Tensor):
-        if frame.dtype != torch.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
-            raise ValueError(f"frame tensor must be uint8 H x W x 3, got {frame.dtype} {tuple(frame.shape)}")
+        if frame.dtype not in (torch.uint8, torch.float16) or frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError(f"frame tensor must be uint8 or float16 H x W x 3, got {frame.dtype} {tuple(frame.shape)}")
         if not frame.is_cuda:
             raise RuntimeError("frame tensor must live on a ROCm device (pass a numpy array for host frames)")
         return frame.contiguous(), False
     a = np.asarray(frame)
-    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
-        raise ValueError(f"frame must be uint8 H x W x 3, got {a.dtype} {a.shape}")
+    if a.dtype not in (np.uint8, np.float16) or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"frame must be uint8 or float16 H x W x 3, got {a.dtype} {a.shape}")
     if not torch.cuda.is_available():
         raise RuntimeError("pythoncrt_amd: no ROCm device visible; there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -398,7 +400,7 @@ def apply_crt_effect(
     quantise.  Returns (out_u8, img_float); img_float is the next call's `state_prev`."""
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
-    eng = _engine(fr.device, h, w)
+    eng = _engine(fr.device, h, w, _lib.PIX_F16 if fr.dtype == torch.float16 else _lib.PIX_U8)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []
@@ -407,7 +409,7 @@ def apply_crt_effect(
         glitch = tables.glitch_offsets_preview(h, w, scanline_phase_px, glitch_amp_px, glitch_height_frac)
     rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold,
                            overlay=text_overlay_rgba, overlay_after=text_overlay_after, glitch=glitch)
-    out = torch.empty((h, w, 3), dtype=torch.uint8, device=fr.device)
+    out = torch.empty((h, w, 3), dtype=fr.dtype, device=fr.device)
     blend = _lib.BLEND_NONE
     if state_prev is not None and persistence > 0.0:                       # ref:687
         prev = _as_device_tensor(state_prev, fr.device, torch.float32, None, "state_prev")
@@ -468,7 +470,7 @@ def apply_static_effects(
     """ref:702-861 — stateless chain; returns the float image (float32 here)."""
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
-    eng = _engine(fr.device, h, w)
+    eng = _engine(fr.device, h, w, _lib.PIX_F16 if fr.dtype == torch.float16 else _lib.PIX_U8)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []

@@ -82,17 +82,20 @@ def baseline_config(n: int) -> Tuple[RenderSettings, int, int]:
         return RenderSettings(**dict(full, bloom_sigma=3.0)), 2160, 3840
     if n == 4:
         return RenderSettings(**dict(full, bloom_sigma=1.2, persistence=0.5)), 1080, 1920
-    raise ValueError(f"BASELINE config {n} is not runnable on this build (config 5 needs fp16 pixels)")
+    if n == 5:      # 8K, as config 3, pixels held as fp16 in and out
+        return RenderSettings(**dict(full, bloom_sigma=3.0)), 4320, 7680
+    raise ValueError(f"unknown BASELINE config {n}")
 
 
 class FramePipeline:
     """One GPU's worth of the render loop."""
 
     def __init__(self, device: torch.device, h: int, w: int, settings: RenderSettings, fps: float = 30.0,
-                 noise_seed: int = 0):
+                 noise_seed: int = 0, dtype: torch.dtype = torch.uint8):
         self.device, self.h, self.w, self.rs, self.fps = device, int(h), int(w), settings, float(fps)
         self.noise_seed = int(noise_seed)
-        self.engine = Engine(device, h, w)
+        self.dtype = dtype                  # torch.uint8, or torch.float16 (half frames on the 0..255 scale)
+        self.engine = Engine(device, h, w, _lib.PIX_F16 if dtype == torch.float16 else _lib.PIX_U8)
         self.static = settings.static_settings(self.h, self.w)
         self.engine.set_params(self.static)
         self.lib = self.engine.lib
@@ -142,7 +145,7 @@ class FramePipeline:
         `state` is the persistence carry (float32 H x W x 3) from the previous run, or None at the
         start of the clip (the first frame then passes through unblended, ref:1094-1095)."""
         n = frames.shape[0]
-        assert frames.dtype == torch.uint8 and tuple(frames.shape[1:]) == (self.h, self.w, 3) and frames.is_contiguous()
+        assert frames.dtype == self.dtype and tuple(frames.shape[1:]) == (self.h, self.w, 3) and frames.is_contiguous()
         if out is None:
             out = torch.empty_like(frames)
         p = float(self.rs.persistence)
@@ -150,7 +153,7 @@ class FramePipeline:
         has_state = state is not None
         if p > 0.0 and state is None:
             state = torch.empty((self.h, self.w, 3), dtype=torch.float32, device=self.device)
-        stride = self.h * self.w * 3
+        stride = self.h * self.w * 3 * frames.element_size()
         with torch.cuda.device(self.device):
             rc = self.lib.crtfx_process_batch(
                 self.engine.ctx, frames.data_ptr(), stride, out.data_ptr(), stride, n, recs,
@@ -184,7 +187,7 @@ class GpuShardEngine:
         self.pipe = pipe
         h, w = pipe.h, pipe.w
         self.local = torch.empty((chunk, h, w, 3), dtype=torch.float32, device=pipe.device)
-        self.out = torch.empty((chunk, h, w, 3), dtype=torch.uint8, device=pipe.device)
+        self.out = torch.empty((chunk, h, w, 3), dtype=pipe.dtype, device=pipe.device)
         self.zero = torch.zeros((h, w, 3), dtype=torch.float32, device=pipe.device)
         self.records = {}
 

@@ -537,3 +537,34 @@ def test_cli_default_settings_chain(pc):
     d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
     assert np.array_equal(out[0].cpu().numpy(), exp[0])     # first frame: no blend yet -> bit-exact
+
+
+# ---- fp16 pixels (BASELINE config 5) -----------------------------------------------------------------------
+
+def f16_frame(h, w, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.random((h, w, 3), dtype=np.float32) * 255.0).astype(np.float16)      # fractional values on the 0..255 scale
+
+
+@pytest.mark.parametrize("cfg", [dict(aberration_px=1), dict(FULL, bloom_sigma=3.0), dict(FULL, bloom_sigma=1.2, triad_preserve_luma=True),
+                                 dict(FULL, bloom_sigma=6.5), dict(FULL, fast_bloom=True, pixel_size=2)])
+def test_fp16_frames(pc, cfg):
+    """A float16 frame is the reference's frame array held as half (ref:569 divides whatever it gets by
+    255.0); the float image is compared as for uint8 frames, the half output frame is |x*255| narrowed."""
+    h, w = 70, 130
+    frame = f16_frame(h, w, 90)
+    plane = np.random.default_rng(91).standard_normal((h, w), dtype=np.float32)
+    got, exp = both_static(pc, frame, cfg, noise_plane=plane if dict(BASE, **cfg)["noise_strength"] > 0 else None)
+    assert_bit_exact(got, exp)
+    c = dict(BASE, **cfg)
+    tm_g = pc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    tm_o = orc.make_triad_mask(h, w, *c["triad"]) if c["triad"] else None
+    vg_g = pc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    vg_o = orc.make_vignette(h, w, c["vignette"]) if c["vignette"] else None
+    kw = dict(noise_plane=plane) if c["noise_strength"] > 0 else {}
+    ug, sg = pc.apply_crt_effect(*crt_args(frame, tm_g, vg_g, 0.0, None, 1.25, c), warp_strength=0.15, **kw)
+    _, so = orc.apply_crt_effect(*crt_args(frame, tm_o, vg_o, 0.0, None, 1.25, c), warp_strength=0.15, **kw)
+    assert ug.dtype == np.float16 and np.abs(sg.astype(np.float64) - so).max() <= 3e-7
+    exp16 = np.abs(so.astype(np.float32) * np.float32(255.0)).astype(np.float16)
+    assert np.abs(ug.astype(np.float32) - exp16.astype(np.float32)).max() <= 0.125      # one half ulp at 128..255
+    assert (ug != exp16).mean() < 5e-3          # half is 32x finer than uint8 around 200: more last-bit flips per float ulp
