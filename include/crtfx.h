@@ -183,8 +183,9 @@ int crtfx_noise_plane(crtfx_ctx* ctx, uint64_t seed, uint64_t frame_index, float
  * quantisation): integer tap origin and packed (fy<<5|fx) fraction per output pixel. */
 int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_dev, void* stream);
 
-/* HIP-event timing of the launches made by the last crtfx_process_batch when profiling is on:
- * kernel 0 = phosphor (grade+bloom+masks+grain), 1 = warp/commit.  Returns mean ms per launch. */
+/* HIP-event timing of the launches while profiling is on (events attached to the dispatch packets):
+ * on = 0 off, 1 every frame, N > 1 every N-th frame (sampling keeps the overhead negligible).
+ * kernel 0 = phosphor (grade+bloom+masks+grain), 1 = warp/commit.  Returns mean ms per timed launch. */
 int crtfx_profile_enable(crtfx_ctx* ctx, int on);
 int crtfx_profile_read(crtfx_ctx* ctx, int kernel, double* mean_ms, int* launches);
 

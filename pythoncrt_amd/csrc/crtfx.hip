@@ -40,6 +40,9 @@ struct crtfx_ctx {
     std::string err;
     // profiling
     bool prof = false;
+    int prof_stride = 1;             // time the launches of every prof_stride-th frame
+    unsigned prof_frame = 0;         // frames seen since profiling was switched on
+    bool prof_this = false;          // the current frame is a sampled one
     std::vector<hipEvent_t> ev[2];   // pairs (start, stop) per launch, per kernel class
     size_t ev_used[2] = {0, 0};
 };
@@ -117,10 +120,12 @@ size_t phosphor_lds_bytes(int R) {
     return floats * sizeof(float);
 }
 
-struct ProfScope {
-    crtfx_ctx* c; int k; hipStream_t s; hipEvent_t stop = nullptr;
-    ProfScope(crtfx_ctx* c_, int k_, hipStream_t s_) : c(c_), k(k_), s(s_) {
-        if (!c->prof) return;
+// A (start, stop) event pair for the next launch of kernel class k, or (nullptr, nullptr) when profiling
+// is off.  The events are attached to the dispatch by CRTFX_LAUNCH, not recorded as separate packets.
+struct ProfEv {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfEv(crtfx_ctx* c, int k) {
+        if (!c->prof || !c->prof_this) return;
         auto& v = c->ev[k];
         size_t& u = c->ev_used[k];
         if (u + 2 > v.size()) {
@@ -128,11 +133,9 @@ struct ProfScope {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
             v.push_back(a); v.push_back(b);
         }
-        (void)hipEventRecord(v[u], s);
-        stop = v[u + 1];
+        e0 = v[u]; e1 = v[u + 1];
         u += 2;
     }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
 size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0);
@@ -165,7 +168,8 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
-    hipLaunchKernelGGL((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, c->kp, kf, ko, c->seg_rows);
+    ProfEv pe(c, 0);
+    CRTFX_LAUNCH((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, pe.e0, pe.e1, c->kp, kf, ko, c->seg_rows);
 }
 
 // Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
@@ -174,7 +178,6 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
     static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr, rr_launch_1, rr_launch_2, rr_launch_3, rr_launch_4,
                                                           rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
                                                           rr_launch_10, rr_launch_11, rr_launch_12};
-    ProfScope ps(c, 0, s);
     // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in
     const bool lean_ok = !c->force_generic && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane &&
                          !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
@@ -187,8 +190,9 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
         const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
         const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
         const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
+        ProfEv pe(c, 0);
         table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs),
-                 phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt), s, variant);
+                 phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt), s, variant, pe.e0, pe.e1);
     } else {
         launch_generic(c, kf, ko, s);
     }
@@ -197,6 +201,7 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
 // The whole chain for one frame.  ko describes the FINAL outputs.
 int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipStream_t s) {
     ko.pix = c->pix_fmt;
+    c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
     if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
     if (!in) return fail(c, CRTFX_E_INVALID, "frame pointer is NULL");
     const uint32_t fl = c->kp.flags;
@@ -223,18 +228,18 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     if (gauss) {
         launch_phosphor(c, kf, k1, s);
     } else {
-        ProfScope ps(c, 0, s);
         if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
             dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4);
             hipLaunchKernelGGL(k_half, gh, dim3(256), 0, s, c->kp, kf);
         }
+        ProfEv pe(c, 0);
         dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-        hipLaunchKernelGGL(k_point, grid, dim3(256), 0, s, c->kp, kf, k1);
+        CRTFX_LAUNCH(k_point, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
     }
     if (two) {
-        ProfScope ps(c, 1, s);
+        ProfEv pe(c, 1);
         dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-        hipLaunchKernelGGL(k_warp, grid, dim3(256), 0, s, c->kp, (const float*)c->pre, ko, warp ? 0 : 1);
+        CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, (const float*)c->pre, ko, warp ? 0 : 1);
     }
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
@@ -422,9 +427,9 @@ int crtfx_blend_quantise(crtfx_ctx* c, const float* static_dev, float* state_ino
     ko.blend = blend;
     ko.p = persistence; ko.q = 1.0 - persistence;
     ko.pix = c->pix_fmt;
-    ProfScope ps(c, 1, (hipStream_t)stream);
+    ProfEv pe(c, 1);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-    hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, static_dev, (const float*)nullptr, 0.0, ko, 0);
+    CRTFX_LAUNCH(k_commit, grid, dim3(256), 0, (hipStream_t)stream, pe.e0, pe.e1, c->H, c->W, static_dev, (const float*)nullptr, 0.0, ko, 0);
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
 }
@@ -438,9 +443,9 @@ int crtfx_halo_correct_quantise(crtfx_ctx* c, const float* local_dev, const floa
     ko.state = state_out_dev;
     ko.blend = CRTFX_BLEND_NONE;
     ko.pix = c->pix_fmt;
-    ProfScope ps(c, 1, (hipStream_t)stream);
+    ProfEv pe(c, 1);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-    hipLaunchKernelGGL(k_commit, grid, dim3(256), 0, (hipStream_t)stream, c->H, c->W, local_dev, carry_in_dev, coeff, ko, 1);
+    CRTFX_LAUNCH(k_commit, grid, dim3(256), 0, (hipStream_t)stream, pe.e0, pe.e1, c->H, c->W, local_dev, carry_in_dev, coeff, ko, 1);
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
 }
@@ -512,6 +517,9 @@ int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, cons
 int crtfx_profile_enable(crtfx_ctx* c, int on) {
     if (!c) return CRTFX_E_INVALID;
     c->prof = on != 0;
+    c->prof_stride = on > 1 ? on : 1;      // on = N > 1: sample every N-th frame (a timed dispatch costs ~8 % when every launch is timed)
+    c->prof_frame = 0;
+    c->prof_this = c->prof;
     c->ev_used[0] = c->ev_used[1] = 0;
     return CRTFX_OK;
 }

@@ -767,7 +767,10 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     if (fl & CRTFX_F_TRIAD) { cm0 = P.triad_row[xc * 3]; cm1 = P.triad_row[xc * 3 + 1]; cm2 = P.triad_row[xc * 3 + 2]; }
     const double cnx2 = row_vig ? P.vig_nx2[xc] : 0.0;
 
+    // the Gaussian taps are symmetric (taps[k] == taps[2R-k] bit for bit: tables.gaussian_taps mirrors them),
+    // so only R+1 of them are ever read: 10 SGPRs instead of 19 live through both blur phases
     const float* taps = P.taps;
+#define TAP(k) taps[(k) <= R ? (k) : 2 * R - (k)]
     float win[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) win[i] = 0.0f;
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             for (int j = 0; j < NB; ++j) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], taps[k], acc);
+                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
                 hcol[j * 3 * TW] = acc;
             }
 #pragma unroll
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int tt = 4 * qq + e - i - off;
-                            if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], taps[tt], acc[i]);
+                            if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], TAP(tt), acc[i]);
                         }
                 }
                 smem4[(NB * 3 * SWS + t * HT) / 4 + (j * 3 + c) * (TW / 4) + gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             for (int j = 0; j < NB; ++j) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], taps[k], acc);
+                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
                 hcol[j * 3 * TW] = acc;
             }
         }
@@ -944,6 +947,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     }
 #endif
 }
+#undef TAP
 
 // ---------------------------------------------------------------------------------------
 // k_warp — barrel warp gather (ref:331-348 + cv2.remap INTER_LINEAR / BORDER_CONSTANT 0),

@@ -165,8 +165,9 @@ class FramePipeline:
         return out, (state if p > 0.0 else None)
 
     # ---- profiling hooks (HIP events recorded by the library on the launch stream) ----------
-    def profile(self, on: bool):
-        _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_profile_enable(self.engine.ctx, 1 if on else 0))
+    def profile(self, on):
+        """on: False/0 off, True/1 time every launch, N > 1 time the launches of every N-th frame."""
+        _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_profile_enable(self.engine.ctx, int(on)))
 
     def profile_read(self):
         out = {}
