@@ -32,7 +32,9 @@ struct crtfx_ctx {
     KParams kp{};
     DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
-    float* pre = nullptr;            // H*W*3 float32 pre-warp scratch
+    float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
+    int pre_frames = 1;
+    int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
     bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
@@ -44,6 +46,7 @@ struct crtfx_ctx {
     unsigned prof_frame = 0;         // frames seen since profiling was switched on
     bool prof_this = false;          // the current frame is a sampled one
     std::vector<hipEvent_t> ev[2];   // pairs (start, stop) per launch, per kernel class
+    std::vector<int> ev_frames[2];   // frames covered by each timed launch
     size_t ev_used[2] = {0, 0};
 };
 
@@ -124,7 +127,7 @@ size_t phosphor_lds_bytes(int R) {
 // is off.  The events are attached to the dispatch by CRTFX_LAUNCH, not recorded as separate packets.
 struct ProfEv {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfEv(crtfx_ctx* c, int k) {
+    ProfEv(crtfx_ctx* c, int k, int frames = 1) {
         if (!c->prof || !c->prof_this) return;
         auto& v = c->ev[k];
         size_t& u = c->ev_used[k];
@@ -134,6 +137,8 @@ struct ProfEv {
             v.push_back(a); v.push_back(b);
         }
         e0 = v[u]; e1 = v[u + 1];
+        if (c->ev_frames[k].size() < u / 2 + 1) c->ev_frames[k].resize(u / 2 + 1);
+        c->ev_frames[k][u / 2] = frames;
         u += 2;
     }
 };
@@ -145,17 +150,18 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0);
 // number of block slots: blocks-per-CU (LDS-limited) x 256 CUs.  Measured (4K, R=9): 128 rows x 1020
 // blocks 103 us; 184 rows x 720 blocks 118 us; 96 rows x 1380 blocks 119 us.  1080p, R=4: 32 rows x 1020
 // blocks 29 us against 34 us at 64 rows — filling the slots beats the extra halo rows; floor 24 rows.
-int pick_seg_rows(int H, int W, int R, int pix = 0) {
+int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
     if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) return ((v + NB - 1) / NB) * NB; }   // tuning experiments
     const int strips = (W + TW - 1) / TW;
     const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
     int bpc = (int)(163840 / lds);
     if (bpc > 4) bpc = 4;      // 4 waves per SIMD is what the register budget allows
     if (bpc < 1) bpc = 1;
-    int segs = (bpc * 256) / strips;
+    int segs = (bpc * 256) / (strips * group);
     if (segs < 1) segs = 1;
     int seg = (H + segs - 1) / segs;
     if (seg < 24) seg = 24;
+    if (seg > 192) seg = 192;      // frames needing several rounds of blocks (8K: seg 184 -> 1554 fps, one-round seg 720 -> 1145 fps)
     seg = ((seg + NB - 1) / NB) * NB;
     const int hmax = ((H + NB - 1) / NB) * NB;
     return seg > hmax ? hmax : seg;
@@ -166,36 +172,55 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
+    const int seg = pick_seg_rows(c->H, c->W, 9, c->pix_fmt, 1);
     const int strips = (c->W + TW - 1) / TW;
-    const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
+    const int segs = (c->H + seg - 1) / seg;
     ProfEv pe(c, 0);
-    CRTFX_LAUNCH((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, pe.e0, pe.e1, c->kp, kf, ko, c->seg_rows);
+    CRTFX_LAUNCH((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, pe.e0, pe.e1, c->kp, kf, ko, seg);
+}
+
+bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
+    // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in; half frames have a lean
+    // build only for the full-chain gate set
+    const int R = c->kp.R;
+    const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane &&
+           !kf.noise_plane && !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
+           ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after && (c->pix_fmt != CRTFX_PIX_F16 || folded);
+}
+
+// g frames (1..MAX_GROUP) through the register-window kernel in one launch.
+void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
+    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr, rr_launch_1, rr_launch_2, rr_launch_3, rr_launch_4,
+                                                          rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
+                                                          rr_launch_10, rr_launch_11, rr_launch_12};
+    const int R = c->kp.R;
+    const int seg = pick_seg_rows(c->H, c->W, R, c->pix_fmt, g);
+    const int strips = (c->W + TW - 1) / TW;
+    const int segs = (c->H + seg - 1) / seg;
+    const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
+    ProfEv pe(c, 0, g);
+    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt),
+             s, variant, pe.e0, pe.e1);
 }
 
 // Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
 // register-window kernel; anything else (radius 0 = 1-tap copy, or > 12) the generic LDS-ring one.
 void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
-    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr, rr_launch_1, rr_launch_2, rr_launch_3, rr_launch_4,
-                                                          rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
-                                                          rr_launch_10, rr_launch_11, rr_launch_12};
-    // the lean kernel has no per-pixel plane loads and no in-kernel blend compiled in
-    const bool lean_ok = !c->force_generic && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane &&
-                         !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
-                         ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after;
-    const int R = c->kp.R;
-    // half frames have a lean build only for the full-chain gate set; anything else takes the generic kernel
-    const bool f16_ok = c->pix_fmt != CRTFX_PIX_F16 || ((c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags);
-    if (lean_ok && f16_ok && R >= 1 && R <= RR_MAX_RADIUS) {
-        const int strips = (c->W + TW - 1) / TW;
-        const int segs = (c->H + c->seg_rows - 1) / c->seg_rows;
-        const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
-        const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
-        ProfEv pe(c, 0);
-        table[R](c->kp, kf, ko, c->seg_rows, dim3(strips, segs),
-                 phosphor_rr_lds_bytes(R, c->seg_rows, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt), s, variant, pe.e0, pe.e1);
+    if (lean_ok(c, kf, ko)) {
+        KGroup kg{};
+        kg.f[0] = kf; kg.o[0] = ko;
+        launch_rr_group(c, kg, 1, s);
     } else {
         launch_generic(c, kf, ko, s);
     }
+}
+
+void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s) {
+    ProfEv pe(c, 1, g);
+    dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
+    CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, identity ? 1 : 0);
 }
 
 // The whole chain for one frame.  ko describes the FINAL outputs.
@@ -237,9 +262,9 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         CRTFX_LAUNCH(k_point, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
     }
     if (two) {
-        ProfEv pe(c, 1);
-        dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-        CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, (const float*)c->pre, ko, warp ? 0 : 1);
+        KWarpGroup wg{};
+        wg.pre[0] = c->pre; wg.o[0] = ko;
+        launch_warp_group(c, wg, 1, !warp, s);
     }
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
@@ -381,6 +406,20 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     c->kp = k;
     c->params_set = true;
     c->seg_rows = pick_seg_rows(H, W, R, c->pix_fmt);
+    {   // frames per grouped launch: as many as fit the resident block slots at ~128-row blocks, at most MAX_GROUP
+        const int strips = (W + TW - 1) / TW;
+        const int bpf = strips * ((H + 127) / 128);
+        int gm = (1024 + bpf / 2) / (bpf > 0 ? bpf : 1);     // measured: 1080p 4 frames/launch 35.5k fps vs 25.5k ungrouped; 4K 1 (2 is 15 % slower)
+        gm = gm < 1 ? 1 : (gm > MAX_GROUP ? MAX_GROUP : gm);
+        if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) gm = v; }
+        if (gm > c->pre_frames) {
+            (void)hipFree(c->pre);
+            c->pre = nullptr;
+            HIP_TRY(c, hipMalloc((void**)&c->pre, (size_t)gm * H * W * 3 * sizeof(float)));
+            c->pre_frames = gm;
+        }
+        c->group_max = gm;
+    }
 
     if (fl & CRTFX_F_BLOOM) {
         const size_t lds = phosphor_lds_bytes(R);
@@ -456,26 +495,79 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
     if (!c) return CRTFX_E_INVALID;
     if (n < 0 || !frames_base || (!out_base && !local_states_base)) return fail(c, CRTFX_E_INVALID, "bad batch arguments");
     if (persistence > 0.0 && !state_inout_dev) return fail(c, CRTFX_E_INVALID, "persistence > 0 needs state_inout_dev");
-    const size_t state_elems = (size_t)c->H * c->W * 3;
-    for (int i = 0; i < n; ++i) {
-        const uint8_t* in = static_cast<const uint8_t*>(frames_base) + (size_t)i * frame_stride_bytes;
+    if (local_states_base && !(persistence > 0.0)) return fail(c, CRTFX_E_INVALID, "local_states_base needs persistence > 0");
+    if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t frame_elems = (size_t)c->H * c->W * 3;
+    const uint32_t fl = c->kp.flags;
+    const bool warp = (fl & CRTFX_F_WARP) != 0;
+    const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);
+    const bool blend_on = persistence > 0.0;
+
+    auto final_out = [&](int i) {
         KOut ko{};
+        ko.pix = c->pix_fmt;
         ko.out_u8 = out_base ? static_cast<uint8_t*>(out_base) + (size_t)i * out_stride_bytes : nullptr;
         ko.p = persistence; ko.q = 1.0 - persistence;
-        if (persistence > 0.0) {
-            ko.state = state_inout_dev;
-            ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE;
-        } else {
-            ko.state = nullptr;
-            ko.blend = CRTFX_BLEND_NONE;
+        if (blend_on) { ko.state = state_inout_dev; ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE; }
+        return ko;
+    };
+    auto frame_in = [&](int i) { return static_cast<const uint8_t*>(frames_base) + (size_t)i * frame_stride_bytes; };
+    auto copy_state = [&](int i) -> int {
+        if (!local_states_base) return CRTFX_OK;
+        HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)i * frame_elems, state_inout_dev, frame_elems * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+        return CRTFX_OK;
+    };
+
+    int i = 0;
+    while (i < n) {
+        // ---- grouped path: Gaussian-bloom chain on the register-window kernel, up to group_max frames per launch ----
+        int g = 0;
+        KGroup kg{};
+        if (gauss) {
+            const int gmax = n - i < c->group_max ? n - i : c->group_max;
+            const bool two = warp || blend_on;
+            for (; g < gmax; ++g) {
+                const crtfx_frame* f = frames ? &frames[i + g] : nullptr;
+                if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev)))
+                    return fail(c, CRTFX_E_INVALID, "scanlines are on but the frame record carries no scan_row_dev / scan_plane_dev");
+                if (f && (f->overlay_rgba_dev || f->glitch_offs_dev)) break;
+                KFrame kf = make_kframe(frame_in(i + g), f);
+                KOut k1{};
+                if (two) { k1.pre = c->pre + (size_t)g * frame_elems; k1.pix = c->pix_fmt; } else k1 = final_out(i + g);
+                k1.dbg = c->dbg;
+                if (!lean_ok(c, kf, k1)) break;
+                kg.f[g] = kf; kg.o[g] = k1;
+            }
+            if (g > 0) {
+                c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
+                launch_rr_group(c, kg, g, s);
+                if (two) {
+                    if (!blend_on) {
+                        KWarpGroup wg{};
+                        for (int j = 0; j < g; ++j) { wg.pre[j] = c->pre + (size_t)j * frame_elems; wg.o[j] = final_out(i + j); }
+                        launch_warp_group(c, wg, g, !warp, s);
+                    } else {                 // the persistence IIR commits frames strictly in order (ref:1081-1105)
+                        for (int j = 0; j < g; ++j) {
+                            KWarpGroup wg{};
+                            wg.pre[0] = c->pre + (size_t)j * frame_elems; wg.o[0] = final_out(i + j);
+                            launch_warp_group(c, wg, 1, !warp, s);
+                            int rc = copy_state(i + j);
+                            if (rc) return rc;
+                        }
+                    }
+                }
+                HIP_TRY(c, hipGetLastError());
+                i += g;
+                continue;
+            }
         }
-        int rc = run_chain(c, in, frames ? &frames[i] : nullptr, ko, (hipStream_t)stream);
+        // ---- general path, one frame ------------------------------------------------------------------------
+        int rc = run_chain(c, frame_in(i), frames ? &frames[i] : nullptr, final_out(i), s);
         if (rc) return rc;
-        if (local_states_base) {
-            if (!ko.state) return fail(c, CRTFX_E_INVALID, "local_states_base needs persistence > 0");
-            HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)i * state_elems, ko.state, state_elems * sizeof(float),
-                                      hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        }
+        if ((rc = copy_state(i))) return rc;
+        ++i;
     }
     return CRTFX_OK;
 }
@@ -533,9 +625,9 @@ int crtfx_profile_read(crtfx_ctx* c, int kernel, double* mean_ms, int* launches)
         HIP_TRY(c, hipEventSynchronize(c->ev[kernel][i + 1]));
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[kernel][i], c->ev[kernel][i + 1]));
-        total += ms; ++cnt;
+        total += ms; cnt += (i / 2 < c->ev_frames[kernel].size()) ? c->ev_frames[kernel][i / 2] : 1;
     }
-    *mean_ms = cnt ? total / cnt : 0.0;
+    *mean_ms = cnt ? total / cnt : 0.0;      // per FRAME: a grouped launch covers several
     *launches = cnt;
     c->ev_used[kernel] = 0;
     return CRTFX_OK;

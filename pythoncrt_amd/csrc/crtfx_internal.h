@@ -8,10 +8,10 @@ namespace crtfx {
 
 // One per radius, each in its own translation unit (crtfx_rr.hip compiled with -DRR_R=n) so the
 // twelve sets of instantiations build in parallel.  variant: 0 = runtime gates (uint8), 1 = SF_FULL gates folded (uint8), 2 = SF_FULL + half frames.
-using rr_launch_fn = void (*)(const KParams&, const KFrame&, const KOut&, int seg_rows, dim3 grid, size_t lds, hipStream_t, int variant,
+using rr_launch_fn = void (*)(const KParams&, const KGroup&, int seg_rows, dim3 grid, size_t lds, hipStream_t, int variant,
                               hipEvent_t ev_start, hipEvent_t ev_stop);
 
-#define CRTFX_RR_DECL(r) void rr_launch_##r(const KParams&, const KFrame&, const KOut&, int, dim3, size_t, hipStream_t, int, hipEvent_t, hipEvent_t);
+#define CRTFX_RR_DECL(r) void rr_launch_##r(const KParams&, const KGroup&, int, dim3, size_t, hipStream_t, int, hipEvent_t, hipEvent_t);
 CRTFX_RR_DECL(1) CRTFX_RR_DECL(2) CRTFX_RR_DECL(3) CRTFX_RR_DECL(4) CRTFX_RR_DECL(5) CRTFX_RR_DECL(6)
 CRTFX_RR_DECL(7) CRTFX_RR_DECL(8) CRTFX_RR_DECL(9) CRTFX_RR_DECL(10) CRTFX_RR_DECL(11) CRTFX_RR_DECL(12)
 #undef CRTFX_RR_DECL

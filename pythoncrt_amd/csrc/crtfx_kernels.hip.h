@@ -87,6 +87,13 @@ struct KOut {
     unsigned long long* dbg;   // CRTFX_STAMP diagnostic build only: per-wave phase cycle sums
 };
 
+// Up to MAX_GROUP frames per launch (blockIdx.z = frame): small frames then fill the block slots of the
+// chip without short, halo-heavy blocks, and fewer launches are needed.  The per-frame records travel by
+// value in the kernel-argument segment and are picked with a wave-uniform index (scalar loads).
+constexpr int MAX_GROUP = 4;
+struct KGroup { KFrame f[MAX_GROUP]; KOut o[MAX_GROUP]; };
+struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; };
+
 // internal gate (set by crtfx_set_params, never by callers): the analytic vignette gain lies in [0,1]
 // (0 <= strength <= 1), so clip(x * gain) of an x in [0,1] is the identity and is skipped.
 constexpr uint32_t KF_VIG_UNIT = 1u << 24;
@@ -708,7 +715,9 @@ constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT |
 // the runtime-flag build needs ~147 VGPRs and would spill under that cap.
 // PIX: pixel format of the frames (folded like the gates); half frames park 2 dwords per centre pixel.
 template <int RT, uint32_t SF, int PIX = 0>
-__global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES)) void k_phosphor_rr(KParams Pin, KFrame F, KOut O, int seg_rows) {
+__global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES)) void k_phosphor_rr(KParams Pin, KGroup G, int seg_rows) {
+    const KFrame F = G.f[blockIdx.z];
+    KOut O = G.o[blockIdx.z];
     KParams P = Pin;
     if constexpr (SF != SF_RUNTIME) P.flags = SF;
     P.pix = PIX;
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     }
 #ifdef CRTFX_STAMP
     if (O.dbg && lane == 0) {
-        unsigned long long* d = O.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        unsigned long long* d = O.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = stamp_sum[i];
     }
 #endif
@@ -1001,7 +1010,9 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
 }
 
 #ifdef CRTFX_MAIN_TU
-__global__ __launch_bounds__(256) void k_warp(KParams P, const float* __restrict__ pre, KOut O, int identity) {
+__global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int identity) {
+    const float* __restrict__ pre = G.pre[blockIdx.z];
+    const KOut O = G.o[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);

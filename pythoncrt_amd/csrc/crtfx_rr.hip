@@ -11,14 +11,14 @@ namespace crtfx {
 #define CRTFX_CAT2(a, b) a##b
 #define CRTFX_CAT(a, b) CRTFX_CAT2(a, b)
 
-void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KFrame& kf, const KOut& ko, int seg_rows, dim3 grid, size_t lds,
+void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_rows, dim3 grid, size_t lds,
                                  hipStream_t s, int variant, hipEvent_t e0, hipEvent_t e1) {
     if (variant == 2)       // half frames, full-chain gates
-        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kf, ko, seg_rows);
+        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else if (variant == 1)
-        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kf, ko, seg_rows);
+        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else
-        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kf, ko, seg_rows);
+        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
 }
 
 }  // namespace crtfx

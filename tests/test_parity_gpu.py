@@ -568,3 +568,38 @@ def test_fp16_frames(pc, cfg):
     exp16 = np.abs(so.astype(np.float32) * np.float32(255.0)).astype(np.float16)
     assert np.abs(ug.astype(np.float32) - exp16.astype(np.float32)).max() <= 0.125      # one half ulp at 128..255
     assert (ug != exp16).mean() < 5e-3          # half is 32x finer than uint8 around 200: more last-bit flips per float ulp
+
+
+@pytest.mark.parametrize("persistence", [0.0, 0.5])
+def test_grouped_batch_equals_frame_by_frame(pc, persistence, monkeypatch):
+    """crtfx_process_batch launches up to 4 frames per grid (blockIdx.z = frame); the frames must come out
+    exactly as when each is rendered by its own call, and in order under the persistence IIR."""
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    monkeypatch.setenv("CRTFX_GROUP", "4")
+    effects._tls.engines = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rs, _, _ = baseline_config(2)
+    rs.persistence = persistence
+    h, w, n = 96, 200, 7
+    frames = torch.from_numpy(np.stack([make_frame(h, w, seed=100 + i, kind="grad") for i in range(n)])).to(dev)
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=9)
+    out, state = pipe.run(frames)
+    tm, vg = pc.make_triad_mask(h, w, rs.triad_strength, rs.triad_softness), pc.make_vignette(h, w, rs.vignette_strength)
+    c = dict(BASE, scanline_strength=rs.scanline_strength, aberration_px=rs.aberration_px, bloom_sigma=rs.bloom_sigma,
+             bloom_strength=rs.bloom_strength, noise_strength=rs.noise_strength)
+    prev = None
+    for i in range(n):
+        st = pc.apply_static_effects(frames[i], c["scanline_strength"], tm, 2.2, False, c["aberration_px"], c["bloom_sigma"], c["bloom_strength"],
+                                     0.0, c["noise_strength"], vg, 2.0, (i / 30.0) * rs.scanline_speed_px_s, False, 1, 0, 0.0,
+                                     time_sec=i / 30.0, warp_strength=rs.warp_strength, noise_seed=9, frame_index=i)
+        if prev is not None and persistence > 0.0:
+            st = torch.clamp(np.float32(persistence) * prev + np.float32(1.0 - persistence) * st, 0.0, 1.0)
+        prev = st
+        u8 = torch.from_numpy(orc.convert_scale_abs(st.cpu().numpy())).to(dev)
+        d = (out[i].to(torch.int16) - u8.to(torch.int16)).abs()
+        if persistence == 0.0:
+            assert torch.equal(out[i], u8), i
+        else:
+            assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3, i     # blend runs in float64 on the GPU
+    effects._tls.engines = {}
