@@ -132,7 +132,14 @@ struct RawRGB { uint32_t r, g, b; };   // the three stored samples of a pixel: b
 // a1 for either pixel format: uint8 -> u/255 (norm_u8); half -> float(h)/255 with a true division
 // (ref:569 `frame.astype(np.float32) / 255.0` applied to a float16 frame array).
 __device__ __forceinline__ float norm_px(int pix, uint32_t s) {
-    if (pix == CRTFX_PIX_F16) return (float)__builtin_bit_cast(_Float16, (unsigned short)s) / 255.0f;
+    if (pix == CRTFX_PIX_F16) {
+        // float(h) / 255.0f by the same corrected reciprocal product as norm_u8: equal to the IEEE quotient for
+        // every finite half (all 63 488 checked, tests/test_parity_gpu.py::test_fp16_normalise_exhaustive)
+        const float f = (float)__builtin_bit_cast(_Float16, (unsigned short)s);
+        const float rcp = 1.0f / 255.0f;
+        const float q = f * rcp;
+        return fmaf(fmaf(-q, 255.0f, f), rcp, q);
+    }
     return norm_u8(s);
 }
 __device__ __forceinline__ RawRGB load_raw(int pix, const uint8_t* __restrict__ in, uint32_t er, uint32_t eg, uint32_t eb) {

@@ -603,3 +603,22 @@ def test_grouped_batch_equals_frame_by_frame(pc, persistence, monkeypatch):
         else:
             assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3, i     # blend runs in float64 on the GPU
     effects._tls.engines = {}
+
+
+def test_fp16_normalise_exhaustive(pc):
+    """Every finite half value / 255.0 (true float32 division) through the kernels' corrected-reciprocal form."""
+    h16 = np.arange(65536, dtype=np.uint16).view(np.float16)
+    h16 = h16[np.isfinite(h16.astype(np.float32))]
+    n = h16.size                        # 63488 = 64 * 992
+    frame = np.stack([h16, h16[::-1], np.roll(h16, 7)], axis=1).reshape(64, n // 64, 3)
+    a = (frame, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0)
+    got = pc.apply_static_effects(*a)
+    exp = frame.astype(np.float32) / 255.0
+    assert got.dtype == np.float32 and np.array_equal(got, exp)
+    # and through the bloom kernels' staging / centre ring (sigma 3 -> lean half build is gate-specific, so this
+    # takes the generic kernel; the lean half build is covered by test_fp16_frames cfg 1)
+    small = frame[:, :130].copy()
+    small = np.abs(small).astype(np.float16)
+    small[small > 255] = 255
+    g2, e2 = both_static(pc, small, dict(bloom_sigma=3.0, bloom_strength=0.25))
+    assert_bit_exact(g2, e2)
