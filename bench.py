@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", type=int, default=3, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[N-1]; 0 = the reference CLI's default flags at 1080p")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 16 at 4K, 32 at 1080p)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
@@ -145,7 +145,7 @@ def main():
         "value": round(fps_out, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{a.config - 1}]: {w}x{h} full chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
+        "config": {"workload": (f"BASELINE configs[{a.config - 1}]" if a.config else "reference CLI defaults (fast bloom, pixel_size 2)") + f": {w}x{h} chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
                                f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, {'fp16' if a.config == 5 else 'u8'} in/out",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
     }

@@ -35,6 +35,11 @@ struct crtfx_ctx {
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
+    // two-stream overlap of k_warp(n) with k_phosphor(n+1): side stream, per-slot events, 2 scratch slots
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
+    bool ev_k2_pending[2] = {false, false};
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
     bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
@@ -299,6 +304,13 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     c->device = device; c->H = height; c->W = width; c->pix_fmt = pix_fmt;
     if (hipMalloc((void**)&c->pre, (size_t)height * width * 3 * sizeof(float)) != hipSuccess) { delete c; return CRTFX_E_NOMEM; }
     c->seg_rows = pick_seg_rows(height, width, 9, pix_fmt);
+    if (const char* ov = getenv("CRTFX_OVERLAP")) c->overlap = ov[0] == '1';
+    if (c->overlap) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->overlap = false;
+        for (int i = 0; i < 2 && c->overlap; ++i)
+            if (hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming) != hipSuccess) c->overlap = false;
+    }
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
@@ -317,6 +329,8 @@ int crtfx_destroy(crtfx_ctx* c) {
                       &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]); if (c->ev_k2[i]) (void)hipEventDestroy(c->ev_k2[i]); }
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return CRTFX_OK;
 }
@@ -412,11 +426,12 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         int gm = (1024 + bpf / 2) / (bpf > 0 ? bpf : 1);     // measured: 1080p 4 frames/launch 35.5k fps vs 25.5k ungrouped; 4K 1 (2 is 15 % slower)
         gm = gm < 1 ? 1 : (gm > MAX_GROUP ? MAX_GROUP : gm);
         if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) gm = v; }
-        if (gm > c->pre_frames) {
+        const int need = c->overlap ? 2 * gm : gm;
+        if (need > c->pre_frames) {
             (void)hipFree(c->pre);
             c->pre = nullptr;
-            HIP_TRY(c, hipMalloc((void**)&c->pre, (size_t)gm * H * W * 3 * sizeof(float)));
-            c->pre_frames = gm;
+            HIP_TRY(c, hipMalloc((void**)&c->pre, (size_t)need * H * W * 3 * sizeof(float)));
+            c->pre_frames = need;
         }
         c->group_max = gm;
     }
@@ -520,7 +535,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         return CRTFX_OK;
     };
 
-    int i = 0;
+    int i = 0, group_no = 0;
     while (i < n) {
         // ---- grouped path: Gaussian-bloom chain on the register-window kernel, up to group_max frames per launch ----
         int g = 0;
@@ -528,6 +543,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         if (gauss) {
             const int gmax = n - i < c->group_max ? n - i : c->group_max;
             const bool two = warp || blend_on;
+            const bool ovl = c->overlap && two;
+            const int slot = ovl ? (group_no & 1) : 0;
             for (; g < gmax; ++g) {
                 const crtfx_frame* f = frames ? &frames[i + g] : nullptr;
                 if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev)))
@@ -535,31 +552,41 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (f && (f->overlay_rgba_dev || f->glitch_offs_dev)) break;
                 KFrame kf = make_kframe(frame_in(i + g), f);
                 KOut k1{};
-                if (two) { k1.pre = c->pre + (size_t)g * frame_elems; k1.pix = c->pix_fmt; } else k1 = final_out(i + g);
+                if (two) { k1.pre = c->pre + ((size_t)slot * c->group_max + g) * frame_elems; k1.pix = c->pix_fmt; } else k1 = final_out(i + g);
                 k1.dbg = c->dbg;
                 if (!lean_ok(c, kf, k1)) break;
                 kg.f[g] = kf; kg.o[g] = k1;
             }
             if (g > 0) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
+                // two-stream overlap: this group's warp/commit kernels run on the side stream, concurrently with the
+                // NEXT group's k_phosphor on the caller's stream (k_warp is gather-latency bound, k_phosphor VALU bound,
+                // and a 42-VGPR warp wave fits beside four 115-VGPR phosphor waves per SIMD).  Two scratch slots.
+                hipStream_t sw = ovl ? c->side : s;
+                if (ovl && c->ev_k2_pending[slot]) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[slot], 0));   // slot free again
                 launch_rr_group(c, kg, g, s);
+                if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k1[slot], s)); HIP_TRY(c, hipStreamWaitEvent(sw, c->ev_k1[slot], 0)); }
                 if (two) {
+                    const float* pre0 = c->pre + (size_t)slot * c->group_max * frame_elems;
                     if (!blend_on) {
                         KWarpGroup wg{};
-                        for (int j = 0; j < g; ++j) { wg.pre[j] = c->pre + (size_t)j * frame_elems; wg.o[j] = final_out(i + j); }
-                        launch_warp_group(c, wg, g, !warp, s);
+                        for (int j = 0; j < g; ++j) { wg.pre[j] = pre0 + (size_t)j * frame_elems; wg.o[j] = final_out(i + j); }
+                        launch_warp_group(c, wg, g, !warp, sw);
                     } else {                 // the persistence IIR commits frames strictly in order (ref:1081-1105)
                         for (int j = 0; j < g; ++j) {
                             KWarpGroup wg{};
-                            wg.pre[0] = c->pre + (size_t)j * frame_elems; wg.o[0] = final_out(i + j);
-                            launch_warp_group(c, wg, 1, !warp, s);
-                            int rc = copy_state(i + j);
-                            if (rc) return rc;
+                            wg.pre[0] = pre0 + (size_t)j * frame_elems; wg.o[0] = final_out(i + j);
+                            launch_warp_group(c, wg, 1, !warp, sw);
+                            if (local_states_base)
+                                HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)(i + j) * frame_elems, state_inout_dev,
+                                                          frame_elems * sizeof(float), hipMemcpyDeviceToDevice, sw));
                         }
                     }
                 }
+                if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k2[slot], sw)); c->ev_k2_pending[slot] = true; }
                 HIP_TRY(c, hipGetLastError());
                 i += g;
+                ++group_no;
                 continue;
             }
         }
@@ -568,6 +595,10 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         if (rc) return rc;
         if ((rc = copy_state(i))) return rc;
         ++i;
+    }
+    if (c->overlap) {      // everything issued on the side stream is ordered before whatever the caller enqueues next
+        for (int k = 0; k < 2; ++k)
+            if (c->ev_k2_pending[k]) { HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[k], 0)); c->ev_k2_pending[k] = false; }
     }
     return CRTFX_OK;
 }

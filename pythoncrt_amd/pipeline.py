@@ -82,6 +82,8 @@ def baseline_config(n: int) -> Tuple[RenderSettings, int, int]:
         return RenderSettings(**dict(full, bloom_sigma=3.0)), 2160, 3840
     if n == 4:
         return RenderSettings(**dict(full, bloom_sigma=1.2, persistence=0.5)), 1080, 1920
+    if n == 0:      # not a BASELINE config: the reference CLI's default flag set (ref:1160-1206) at 1080p
+        return RenderSettings(), 1080, 1920
     if n == 5:      # 8K, as config 3, pixels held as fp16 in and out
         return RenderSettings(**dict(full, bloom_sigma=3.0)), 4320, 7680
     raise ValueError(f"unknown BASELINE config {n}")
