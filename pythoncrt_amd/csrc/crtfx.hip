@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,8 @@ struct crtfx_ctx {
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
+    int group_seg = 128;             // rows per block when a full group is launched (plan_grid)
+    int seg_for[MAX_GROUP + 1] = {0, 0, 0, 0, 0};   // planned rows per block for a (partial) group of g frames
     // two-stream overlap of k_warp(n) with k_phosphor(n+1): side stream, per-slot events, 2 scratch slots
     bool overlap = false;
     hipStream_t side = nullptr;
@@ -172,8 +175,53 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
     return seg > hmax ? hmax : seg;
 }
 
+// Launch-shape planner for k_phosphor_rr.  A block of `rows` output rows costs ceil((rows + 2R) / NB) loop
+// iterations (+ a fixed prologue); blocks are dealt in dispatch order (x fastest, then row segment, then frame)
+// onto bpc x 256 resident slots.  For every candidate (frames per grid g, rows per block seg) the makespan of that
+// list schedule is simulated and the pair with the fewest iterations PER FRAME wins.  This reproduces the
+// measured landscape (4K, R = 9: g=1/seg=128 -> 19 it/frame = 89 us; g=2/seg=256 -> 17.5 = 82.5 us, the short
+// last-segment blocks freeing slots for the overflow; g=2/seg=240 -> two full rounds = 103 us).
+struct GridPlan { int g, seg; };
+GridPlan plan_grid(int H, int W, int R, int pix, int gmin, int gmax_allowed) {
+    const int strips = (W + TW - 1) / TW;
+    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
+    int bpc = (int)(163840 / lds);
+    bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+    const int slots = bpc * 256;
+    const int hcap = ((H + NB - 1) / NB) * NB;
+    GridPlan best{1, hcap < 128 ? hcap : 128};
+    double best_cost = 1e30;
+    std::priority_queue<double, std::vector<double>, std::greater<double>> freeat;
+    for (int g = gmin; g <= gmax_allowed; ++g) {
+        for (int seg = 24; seg <= hcap && seg <= 256; seg += NB) {      // taller blocks lose more than the model sees (8K: 688 rows 474 us, 224 rows 426 us)
+            const int segs = (H + seg - 1) / seg;
+            const long nblk = (long)strips * segs * g;
+            if (nblk > 8L * slots && seg < 184) continue;           // far too many tiny blocks: not worth simulating
+            // list scheduling in dispatch order; all blocks of one (frame, segment) row share a duration
+            while (!freeat.empty()) freeat.pop();
+            for (int k = 0; k < slots; ++k) freeat.push(0.0);
+            double makespan = 0.0;
+            for (int z = 0; z < g; ++z)
+                for (int ys = 0; ys < segs; ++ys) {
+                    const int rows = (ys == segs - 1) ? H - ys * seg : seg;
+                    const double d = (double)((rows + 2 * R + NB - 1) / NB) + 1.5;
+                    for (int x = 0; x < strips; ++x) {
+                        const double t = freeat.top() + d;      // the earliest-free slot takes the next block
+                        freeat.pop();
+                        freeat.push(t);
+                        if (t > makespan) makespan = t;
+                    }
+                }
+            double cost = makespan / g;
+            if (g > 1) cost *= 1.0 + 0.01 * (g - 1);                // mild preference for small groups (scratch stays cache-sized)
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = GridPlan{g, seg}; }
+        }
+    }
+    return best;
+}
+
 size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
-    return ((size_t)rr_lds_fixed_floats(R, pix) + (size_t)seg_rows * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
+    return ((size_t)rr_lds_fixed_floats(R, pix) + 16 * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -200,7 +248,8 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
                                                           rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
                                                           rr_launch_10, rr_launch_11, rr_launch_12};
     const int R = c->kp.R;
-    const int seg = pick_seg_rows(c->H, c->W, R, c->pix_fmt, g);
+    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, g, g).seg;   // partial last group / single frames: planned once
+    const int seg = c->seg_for[g];
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
     const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
@@ -420,20 +469,26 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     c->kp = k;
     c->params_set = true;
     c->seg_rows = pick_seg_rows(H, W, R, c->pix_fmt);
-    {   // frames per grouped launch: as many as fit the resident block slots at ~128-row blocks, at most MAX_GROUP
-        const int strips = (W + TW - 1) / TW;
-        const int bpf = strips * ((H + 127) / 128);
-        int gm = (1024 + bpf / 2) / (bpf > 0 ? bpf : 1);     // measured: 1080p 4 frames/launch 35.5k fps vs 25.5k ungrouped; 4K 1 (2 is 15 % slower)
-        gm = gm < 1 ? 1 : (gm > MAX_GROUP ? MAX_GROUP : gm);
-        if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) gm = v; }
-        const int need = c->overlap ? 2 * gm : gm;
+    {   // launch shape of the grouped path: frames per grid and rows per block from the planner
+        // keep the float32 scratch of a whole group inside the 256 MiB Infinity Cache (k_warp reads it right back:
+        // 4K with 4 frames per grid = 398 MB and k_warp goes from 38 to 44 us per frame)
+        int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
+        gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
+        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, 1, gcap);
+        if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) { gp.g = v; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, v); } }
+        if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) gp.seg = ((v + NB - 1) / NB) * NB; }
+        const int need = c->overlap ? 2 * gp.g : gp.g;
         if (need > c->pre_frames) {
             (void)hipFree(c->pre);
             c->pre = nullptr;
             HIP_TRY(c, hipMalloc((void**)&c->pre, (size_t)need * H * W * 3 * sizeof(float)));
             c->pre_frames = need;
         }
-        c->group_max = gm;
+        c->group_max = gp.g;
+        c->group_seg = gp.seg;
+        if (getenv("CRTFX_DEBUG_PLAN")) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block\n", W, H, R, gp.g, gp.seg);
+        for (int g = 1; g <= MAX_GROUP; ++g) c->seg_for[g] = 0;
+        c->seg_for[gp.g] = gp.seg;
     }
 
     if (fl & CRTFX_F_BLOOM) {

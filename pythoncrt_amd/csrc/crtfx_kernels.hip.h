@@ -748,8 +748,8 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     float* hrow = stg + NB * 3 * SWS;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
     uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // [CR][TW] packed centre pixels
-    uint32_t* rowtab = cring + CR * TW * CRW;                              // [seg_rows][3]: scan gain bits, ny2 lo, ny2 hi
-    int* ytab = reinterpret_cast<int*>(rowtab + seg_rows * 3);             // [seg_rows + 2R]: source row of halo row (pixelate)
+    uint32_t* rowtab = cring + CR * TW * CRW;                              // [16][3] ring: scan gain bits, ny2 lo, ny2 hi of output row y at (y - y_begin) & 15
+    int* ytab = reinterpret_cast<int*>(rowtab + 16 * 3);                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -768,12 +768,6 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     // plane — triad_full, scan_plane, vig_full, noise_plane — and no in-kernel blend is in play)
     const bool row_scan = (fl & CRTFX_F_SCANLINES) != 0;
     const bool row_vig = (fl & CRTFX_F_VIGNETTE) != 0;
-    for (int i = tid; i < y_end - y_begin; i += RR_THREADS) {
-        rowtab[i * 3] = __float_as_uint(row_scan ? F.scan_row[y_begin + i] : 1.0f);
-        const double n2 = row_vig ? P.vig_ny2[y_begin + i] : 0.0;
-        rowtab[i * 3 + 1] = (uint32_t)__double2loint(n2);
-        rowtab[i * 3 + 2] = (uint32_t)__double2hiint(n2);
-    }
     const bool pixelate = (fl & CRTFX_F_PIXELATE) != 0;
     if (pixelate)
         for (int i = tid; i < y_end - y_begin + 2 * R; i += RR_THREADS) ytab[i] = P.ymap[min(max(y_begin - R + i, 0), H - 1)];
@@ -813,9 +807,18 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     }
     __syncthreads();                                // ytab / rowtab / lut visible
     RawRGB raw[A_ITEMS];
+    float pf_scan = 1.0f;                                  // per-row constants of output row hb - R + tid (threads < NB),
+    double pf_ny2 = 0.0;                                   // requested one iteration ahead like the pixel bytes
     const uint32_t row_bytes = (uint32_t)W * 3u;           // elements per frame row
     auto prefetch = [&](int hb) {
         const int nrows = min(NB, y_end + R - hb);
+        {
+            const int yr = hb - R + tid;
+            if (tid < NB && yr >= y_begin && yr < y_end) {
+                if (row_scan) pf_scan = F.scan_row[yr];
+                if (row_vig) pf_ny2 = P.vig_ny2[yr];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < A_ITEMS; ++u) {
             const int it = tid + u * RR_THREADS;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
                     uint32_t s0, s1, s2;
                     if constexpr (PIX) { const uint32_t lo = cp[0]; s0 = lo & 0xFFFFu; s1 = lo >> 16; s2 = cp[1]; }
                     else { const uint32_t pk = cp[0]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
-                    const uint32_t* rt = rowtab + (y - y_begin) * 3;
+                    const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 3;
                     M.sl = __uint_as_float(rt[0]);
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
                     r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
@@ -883,6 +886,13 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
         }
         STAMP(4);
         // ---- A(n): grade the prefetched halo rows [hb, hb+nrows) into the staging tile ----------
+        {
+            const int yr = hb - R + tid;                     // output row whose constants arrived with this block's bytes
+            if (tid < NB && yr >= y_begin && yr < y_end) {
+                uint32_t* rt = rowtab + ((yr - y_begin) & 15) * 3;
+                rt[0] = __float_as_uint(pf_scan); rt[1] = (uint32_t)__double2loint(pf_ny2); rt[2] = (uint32_t)__double2hiint(pf_ny2);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < A_ITEMS; ++u) {
             const int it = tid + u * RR_THREADS;
