@@ -151,22 +151,33 @@ def main():
     }
     if rank == 0:
         if kt:
-            ms_frame = sum(v[0] for v in kt.values() if v[1])
-            dom = max(kt.items(), key=lambda kv: kv[1][0])
-            achieved = alg_bytes_frame / (ms_frame * 1e-3) / 1e9
+            # kt[k] = (mean ms per launch, timed launches, frames they covered): a launch of the dominant kernel
+            # covers fpl frames (crtfx_process_batch groups frames per grid), so everything below is quoted PER LAUNCH
+            # of that kernel = per group of fpl frames, with the other kernel's launches over the same frames added.
+            kt = {k: v for k, v in kt.items() if v[1]}
+            per_frame_ms = {k: v[0] * v[1] / v[2] for k, v in kt.items()}
+            dom = max(per_frame_ms, key=per_frame_ms.get)
+            fpl = kt[dom][2] / kt[dom][1]
+            group_ms = sum(per_frame_ms.values()) * fpl
+            alg_launch = alg_bytes_frame * fpl
+            achieved = alg_launch / (group_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"config{a.config}")
+                    t_frame = json.load(open(tpath)).get(f"config{a.config}")        # PMC bytes per frame (tools/summarise_profiles.py)
+                    traffic = int(t_frame * fpl) if t_frame else None
                 except Exception:
                     traffic = None
             res["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "per-frame chain k_phosphor -> k_warp (algorithmic bytes of the whole frame / summed kernel time)",
-                "algorithmic_bytes_per_frame": alg_bytes_frame, "dominant_kernel": dom[0],
-                "kernels_ms": {k: round(v[0], 4) for k, v in kt.items()}, "launches": {k: v[1] for k, v in kt.items()},
+                "kernel": f"{dom} (+ the other kernel of the chain over the same frames): algorithmic bytes of the frames of one launch / their summed kernel time",
+                "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_launch": int(alg_launch),
+                "algorithmic_bytes_per_frame": alg_bytes_frame, "chain_ms_per_launch_group": round(group_ms, 4),
+                "dominant_kernel": dom,
+                "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
+                            for k, v in kt.items()},
             }
         if world == 1 and a.cpu_frames != 0 and a.config != 5:
             n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work

@@ -185,9 +185,11 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
 
 /* HIP-event timing of the launches while profiling is on (events attached to the dispatch packets):
  * on = 0 off, 1 every frame, N > 1 every N-th frame (sampling keeps the overhead negligible).
- * kernel 0 = phosphor (grade+bloom+masks+grain), 1 = warp/commit.  Returns mean ms per timed launch. */
+ * kernel 0 = phosphor (grade+bloom+masks+grain), 1 = warp/commit.  Returns the mean duration of the timed
+ * launches (what `rocprofv3 --kernel-trace --stats` reports as AverageNs), their count, and (frames may be NULL)
+ * the number of frames they covered: crtfx_process_batch puts several frames into one grid. */
 int crtfx_profile_enable(crtfx_ctx* ctx, int on);
-int crtfx_profile_read(crtfx_ctx* ctx, int kernel, double* mean_ms, int* launches);
+int crtfx_profile_read(crtfx_ctx* ctx, int kernel, double* mean_launch_ms, int* launches, int* frames);
 
 /* Host-side helper (no GPU work): horizontal Gaussian softening of ONE mask row with
  * BORDER_REPLICATE, taps accumulated in order with fmaf — the (k,1) cv2.GaussianBlur of

@@ -702,19 +702,21 @@ int crtfx_profile_enable(crtfx_ctx* c, int on) {
     return CRTFX_OK;
 }
 
-int crtfx_profile_read(crtfx_ctx* c, int kernel, double* mean_ms, int* launches) {
-    if (!c || kernel < 0 || kernel > 1 || !mean_ms || !launches) return CRTFX_E_INVALID;
+int crtfx_profile_read(crtfx_ctx* c, int kernel, double* mean_launch_ms, int* launches, int* frames) {
+    if (!c || kernel < 0 || kernel > 1 || !mean_launch_ms || !launches) return CRTFX_E_INVALID;
     const size_t u = c->ev_used[kernel];
     double total = 0.0;
-    int cnt = 0;
+    int cnt = 0, fr = 0;
     for (size_t i = 0; i + 1 < u; i += 2) {
         HIP_TRY(c, hipEventSynchronize(c->ev[kernel][i + 1]));
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[kernel][i], c->ev[kernel][i + 1]));
-        total += ms; cnt += (i / 2 < c->ev_frames[kernel].size()) ? c->ev_frames[kernel][i / 2] : 1;
+        total += ms; ++cnt;
+        fr += (i / 2 < c->ev_frames[kernel].size()) ? c->ev_frames[kernel][i / 2] : 1;      // a grouped launch covers several frames
     }
-    *mean_ms = cnt ? total / cnt : 0.0;      // per FRAME: a grouped launch covers several
+    *mean_launch_ms = cnt ? total / cnt : 0.0;
     *launches = cnt;
+    if (frames) *frames = fr;
     c->ev_used[kernel] = 0;
     return CRTFX_OK;
 }

@@ -174,9 +174,10 @@ class FramePipeline:
     def profile_read(self):
         out = {}
         for k, name in ((0, "k_phosphor"), (1, "k_warp")):
-            ms, cnt = ctypes.c_double(), ctypes.c_int()
-            _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_profile_read(self.engine.ctx, k, ctypes.byref(ms), ctypes.byref(cnt)))
-            out[name] = (ms.value, cnt.value)
+            ms, cnt, fr = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+            _lib.check(self.lib, self.engine.ctx,
+                       self.lib.crtfx_profile_read(self.engine.ctx, k, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fr)))
+            out[name] = (ms.value, cnt.value, fr.value)      # mean ms per launch, timed launches, frames they covered
         return out
 
 
