@@ -175,6 +175,11 @@ int crtfx_process_batch(crtfx_ctx* ctx, const void* frames_base, size_t frame_st
                         float* state_inout_dev, double persistence, int first_has_state,
                         float* local_states_base, void* stream);
 
+/* cv2.resize(state_prev, (W, H), INTER_LINEAR) of ref:689-690: the previous persistence state has another
+ * size than this ctx's frames (the preview window was resized between ticks).  src_dev: src_h x src_w x 3
+ * float32; dst_dev: H x W x 3 float32, then usable as state_inout_dev of crtfx_apply. */
+int crtfx_resize_state(crtfx_ctx* ctx, const float* src_dev, int src_h, int src_w, float* dst_dev, void* stream);
+
 /* The N(0,1) plane the in-kernel counter-based RNG draws for (seed, frame_index): lets a test
  * feed the identical grain to the CPU oracle (cv2.randn, ref:641,645, is unreproducible). */
 int crtfx_noise_plane(crtfx_ctx* ctx, uint64_t seed, uint64_t frame_index, float* out_dev, void* stream);

@@ -202,6 +202,49 @@ int orc_resize_linear_f32(const float* src, int sh, int sw, float* dst, int dh, 
     return 0;
 }
 
+/* cv2.resize INTER_LINEAR for CV_64F (the persistence state of a promoted chain, ref:690): same
+ * offsets and FLOAT coefficients as the 32F path (the alpha/beta tables are float for every depth),
+ * arithmetic in double (HResizeLinear<double,double,float>, VResizeLinear<double,double,float>);
+ * exact 2x decimation goes through resizeAreaFast with a double work type. */
+int orc_resize_linear_f64(const double* src, int sh, int sw, double* dst, int dh, int dw, int cn)
+{
+    if (dw * 2 == sw && dh * 2 == sh) {
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < cn; ++c) {
+                    const double* p = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+                    const double* q = p + (size_t)sw * cn;
+                    dst[((size_t)y * dw + x) * cn + c] = (p[0] + p[cn] + q[0] + q[cn]) * 0.25;
+                }
+        return 0;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    for (int y = 0; y < dh; ++y) {
+        float fy = (float)((y + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        const int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+        const float b1 = fy, b0 = 1.0f - fy;
+        for (int x = 0; x < dw; ++x) {
+            float fx = (float)((x + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            const float a1 = fx, a0 = 1.0f - fx;
+            for (int c = 0; c < cn; ++c) {
+                const double r0 = src[((size_t)sy * sw + sx) * cn + c] * (double)a0 + src[((size_t)sy * sw + sx1) * cn + c] * (double)a1;
+                const double r1 = src[((size_t)sy1 * sw + sx) * cn + c] * (double)a0 + src[((size_t)sy1 * sw + sx1) * cn + c] * (double)a1;
+                dst[((size_t)y * dw + x) * cn + c] = r0 * (double)b0 + r1 * (double)b1;
+            }
+        }
+    }
+    return 0;
+}
+
 /* cv2.convertScaleAbs(alpha=255, beta=0): the 32f and 64f sources both go through the float
  * work type (cvtabs_32f): u8 = saturate(cvRound(|(float)x * 255.0f + 0|)). */
 int orc_convert_scale_abs_f32(const float* src, uint8_t* dst, size_t n, float alpha)

@@ -60,6 +60,7 @@ def _lib():
     lib.orc_remap_bilinear_f64.argtypes = [dp, dp, ci, ci, ci, fp, fp]
     lib.orc_resize_nearest_f32.argtypes = [fp, ci, ci, fp, ci, ci, ci]
     lib.orc_resize_linear_f32.argtypes = [fp, ci, ci, fp, ci, ci, ci]
+    lib.orc_resize_linear_f64.argtypes = [dp, ci, ci, dp, ci, ci, ci]
     lib.orc_convert_scale_abs_f32.argtypes = [fp, up, ctypes.c_size_t, ctypes.c_float]
     lib.orc_convert_scale_abs_f64.argtypes = [dp, up, ctypes.c_size_t, ctypes.c_float]
     lib.orc_add_weighted_f32.argtypes = [fp, ctypes.c_float, fp, ctypes.c_float, fp, ctypes.c_size_t]
@@ -180,8 +181,16 @@ def remap_bilinear(img: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.
 
 
 def resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: str) -> np.ndarray:
-    """cv2.resize(img, (dw, dh), interpolation=INTER_NEAREST|INTER_LINEAR) for CV_32F."""
+    """cv2.resize(img, (dw, dh), interpolation=INTER_NEAREST|INTER_LINEAR) for CV_32F; INTER_LINEAR also for
+    CV_64F (the float64 persistence state of a promoted chain, ref:690)."""
     dw, dh = int(dsize[0]), int(dsize[1])
+    if interpolation == "linear" and img.dtype == np.float64:
+        src = np.ascontiguousarray(img)
+        sh, sw = src.shape[:2]
+        dst = np.empty((dh, dw) + src.shape[2:], np.float64)
+        rc = _lib().orc_resize_linear_f64(_dp(src), sh, sw, _dp(dst), dh, dw, 1 if src.ndim == 2 else src.shape[2])
+        assert rc == 0
+        return dst
     src = np.ascontiguousarray(img, np.float32)
     sh, sw = src.shape[:2]
     cn = 1 if src.ndim == 2 else src.shape[2]
@@ -389,10 +398,12 @@ def bloom_ksize(bloom_sigma: float) -> int:
 
 
 def _overlay(img, ov, h, w):
-    """ref:588-598 / :653-663 (shape-mismatch PIL resize not restated: caller passes H x W)."""
+    """ref:588-598 / :653-663, including the Pillow bilinear resize of an overlay of another size (ref:593-594)."""
     if ov.dtype != np.uint8:
         ov = np.clip(ov, 0, 255).astype(np.uint8)
-    assert ov.shape[0] == h and ov.shape[1] == w, "overlay must be frame-sized in the oracle"
+    if ov.shape[0] != h or ov.shape[1] != w:
+        from PIL import Image
+        ov = np.asarray(Image.fromarray(ov, mode="RGBA").resize((w, h), Image.BILINEAR))
     alpha = (ov[:, :, 3:4].astype(np.float32)) / 255.0
     rgb = ov[:, :, :3].astype(np.float32) / 255.0
     return np.clip(img * (1.0 - alpha) + rgb * alpha, 0.0, 1.0)

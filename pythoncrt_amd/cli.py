@@ -10,8 +10,12 @@ pipe), from a file or stdin/stdout, so the drop-in sits between two ffmpeg proce
       python -m pythoncrt_amd.cli --input - --width 1920 --height 1080 --fps 30 --output - [effect flags] |
       ffmpeg -f rawvideo -pix_fmt rgb24 -s 1920x1080 -r 30 -i - out.mp4
 
-`--gui`, `--gpu`, `--nvenc-preset`, `--encoder`, `--decoder`, `--crf`, `--bitrate` and the `--text*`
-flags are accepted for compatibility and ignored (encode/decode/UI are not part of this path).
+`--gui`, `--gpu`, `--nvenc-preset`, `--encoder`, `--decoder`, `--crf` and `--bitrate` are accepted for
+compatibility and ignored (encode/decode/UI are not part of this path).  `--text*` rasterise the overlay on
+the host with Pillow (ref:366-414) and alpha-blend it on the GPU before or after the effects.
+
+Host staging: two pinned input and two pinned output batches; batch k's upload, kernels
+and download are enqueued on one stream while the host writes batch k-1 and reads batch k+1.
 """
 from __future__ import annotations
 
@@ -116,17 +120,27 @@ def settings_from_args(a):
     )
 
 
+def _read_into(fin, view: memoryview) -> int:
+    """Fill `view` from a file or pipe; returns the bytes read (short only at end of stream)."""
+    got = 0
+    while got < len(view):
+        k = fin.readinto(view[got:])
+        if not k:
+            break
+        got += k
+    return got
+
+
 def main(argv=None) -> int:
     a = build_parser().parse_args(argv)
     if a.gui or not a.input:
         raise SystemExit("the GUI is not part of this path; pass --input (raw rgb24 file or '-')")
     if a.width <= 0 or a.height <= 0:
         raise SystemExit("raw rgb24 input needs --width and --height")
-    if a.text:
-        raise SystemExit("--text: overlay rasterisation is not built yet (SURVEY 8f row 1)")
     import os
     import torch
     from .pipeline import FramePipeline
+    from .text import make_text_overlay_rgba
     rs = settings_from_args(a)
     fps_out = int(a.fps) if a.fps and a.fps > 0 else 24            # ref:914
     h, w = int(a.height), int(a.width)
@@ -134,24 +148,50 @@ def main(argv=None) -> int:
         raise SystemExit("no ROCm device visible; pythoncrt_amd has no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
     seed = a.noise_seed if a.noise_seed is not None else int.from_bytes(os.urandom(8), "little")
-    pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=seed)
-    fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb")
+    overlay = make_text_overlay_rgba(w, h, a.text, a.text_font, a.text_size, a.text_color, (a.text_x, a.text_y)) if a.text else None   # ref:1076
+    pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=seed, text_overlay_rgba=overlay, text_overlay_after=bool(a.text_after))
+    fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb", buffering=0)
     out_path = a.output if a.output else (a.input + "_crt.rgb" if a.input != "-" else "-")
     fout = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
+    B = max(1, int(a.batch))
     frame_bytes = h * w * 3
+    host_in = [torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    host_out = [torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    dev_out = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
     t0 = time.perf_counter()
-    state, index = None, 0
+    state, index, k = None, 0, 0
+    pending = None                                                  # (slot, frames) of the batch still in flight
+
+    def drain(p):
+        slot, n = p
+        done[slot].synchronize()
+        fout.write(memoryview(host_out[slot].numpy()).cast("B")[: n * frame_bytes])
+
     while True:
-        buf = fin.read(frame_bytes * a.batch)
-        n = len(buf) // frame_bytes
-        if n == 0:
-            break
-        frames = torch.frombuffer(bytearray(buf[: n * frame_bytes]), dtype=torch.uint8).view(n, h, w, 3).to(dev)
-        out, state = pipe.run(frames, first_index=index, state=state)
-        fout.write(out.cpu().numpy().tobytes())
+        slot = k & 1
+        got = _read_into(fin, memoryview(host_in[slot].numpy()).cast("B"))
+        n = got // frame_bytes                                      # a trailing partial frame is dropped, as ffmpeg's rawvideo demuxer does
+        if n:
+            dev_in[slot][:n].copy_(host_in[slot][:n], non_blocking=True)
+            _, state = pipe.run(dev_in[slot][:n], first_index=index, state=state, out=dev_out[slot][:n])
+            host_out[slot][:n].copy_(dev_out[slot][:n], non_blocking=True)
+            done[slot].record()
+        if pending is not None:
+            drain(pending)
+        pending = (slot, n) if n else None
         index += n
+        k += 1
+        if n < B:
+            break
+    if pending is not None:
+        drain(pending)
+    fout.flush()
     if fout is not sys.stdout.buffer:
         fout.close()
+    if fin is not sys.stdin.buffer:
+        fin.close()
     print(f"{index} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)      # ref:1269
     return 0
 

@@ -676,6 +676,22 @@ int crtfx_warp_map(crtfx_ctx* c, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_
     return CRTFX_OK;
 }
 
+int crtfx_resize_state(crtfx_ctx* c, const float* src_dev, int src_h, int src_w, float* dst_dev, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (!src_dev || !dst_dev || src_h <= 0 || src_w <= 0) return fail(c, CRTFX_E_INVALID, "bad resize arguments");
+    if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
+    if (src_h > 32767 || src_w > 32767) return fail(c, CRTFX_E_UNSUPPORTED, "state of %dx%d exceeds 32767", src_w, src_h);
+    const double sx = (double)src_w / c->W, sy = (double)src_h / c->H;
+    dim3 grid((c->W + 255) / 256, c->H);
+    // the reference's state is float64 exactly when its chain promotes (vignette / flicker: DESIGN.md 3)
+    if (c->kp.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER))
+        hipLaunchKernelGGL(k_resize_state<double>, grid, dim3(256), 0, (hipStream_t)stream, src_dev, src_h, src_w, dst_dev, c->H, c->W, sx, sy);
+    else
+        hipLaunchKernelGGL(k_resize_state<float>, grid, dim3(256), 0, (hipStream_t)stream, src_dev, src_h, src_w, dst_dev, c->H, c->W, sx, sy);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
 int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, const float* taps, int ntaps) {
     if (!row_in || !row_out || !taps || w <= 0 || cn <= 0 || ntaps <= 0 || !(ntaps & 1)) return CRTFX_E_INVALID;
     const int r = ntaps / 2;

@@ -751,7 +751,11 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     uint32_t* rowtab = cring + CR * TW * CRW;                              // [16][3] ring: scan gain bits, ny2 lo, ny2 hi of output row y at (y - y_begin) & 15
     int* ytab = reinterpret_cast<int*>(rowtab + 16 * 3);                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
-    const int tid = threadIdx.x;
+    // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
+    // prefetches).  Rotating the roles by the block's dispatch number spreads them over the SIMDs of a CU: measured
+    // 4K 165.1 us per 2-frame launch without, 161.6 with the low bits (>>3: 161.5, >>5: 163.1, >>8: 171.9).
+    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int tid = (threadIdx.x + ((wg_lin & 3) << 6)) & (RR_THREADS - 1);
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int H = P.H, W = P.W;
@@ -1069,6 +1073,54 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int ident
     }
     if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), packed);
 }
+#endif  // CRTFX_MAIN_TU
+
+#ifdef CRTFX_MAIN_TU
+// crtfx_resize_state — cv2.resize(state_prev, (W, H), INTER_LINEAR) of ref:690: the previous persistence state
+// arrives with another size (the preview window was resized between ticks).  OpenCV: source offset and FLOAT
+// coefficient per axis from fx = (float)((d + 0.5) * scale - 0.5) (clamped to the edges with coefficient 0), the
+// horizontal lerp of the two source rows first, then the vertical one, in the work type T (float for a float32
+// state; double for the float64 state of a promoted chain, whose values the GPU holds rounded to float32);
+// exact 2x decimation is OpenCV's area fast path, (a + b + c + d) * 0.25.
+template <typename T>
+__device__ __forceinline__ void resize_axis(int d, double scale, int n, int& s0, int& s1, T& c0, T& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= n - 1) { f = 0.0f; s = n - 1; }
+    s0 = s; s1 = min(s + 1, n - 1);
+    c1 = (T)f; c0 = (T)(1.0f - f);
+}
+
+template <typename T>
+__global__ void k_resize_state(const float* __restrict__ src, int sh, int sw, float* __restrict__ dst, int dh, int dw,
+                               double scale_x, double scale_y) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    float* o = dst + ((size_t)y * dw + x) * 3;
+    if (dw * 2 == sw && dh * 2 == sh) {
+        const float* p = src + ((size_t)(2 * y) * sw + 2 * x) * 3;
+        const float* q = p + (size_t)sw * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (float)(((((T)p[c] + (T)p[3 + c]) + (T)q[c]) + (T)q[3 + c]) * (T)0.25);
+        return;
+    }
+    int x0, x1, y0, y1;
+    T a0, a1, b0, b1;
+    resize_axis<T>(x, scale_x, sw, x0, x1, a0, a1);
+    resize_axis<T>(y, scale_y, sh, y0, y1, b0, b1);
+    const float* r0 = src + (size_t)y0 * sw * 3;
+    const float* r1 = src + (size_t)y1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T h0 = (T)r0[x0 * 3 + c] * a0 + (T)r0[x1 * 3 + c] * a1;
+        const T h1 = (T)r1[x0 * 3 + c] * a0 + (T)r1[x1 * 3 + c] * a1;
+        o[c] = (float)(h0 * b0 + h1 * b1);
+    }
+}
+
 #endif  // CRTFX_MAIN_TU
 
 // crtfx_warp_map — the integer sampling map alone (parity: bit-exact against the oracle).

@@ -272,19 +272,20 @@ class Engine:
 
 
 def _overlay_tensor(ov, device, h, w) -> torch.Tensor:
-    """ref:590-594 — non-uint8 overlays are clipped to 0..255 and cast; a size mismatch would go through
-    PIL's bilinear resize in the reference (cold path, not built)."""
+    """ref:590-594 — non-uint8 overlays are clipped to 0..255 and cast; an overlay of another size goes
+    through Pillow's bilinear resize on the host exactly as in the reference (text.fit_overlay)."""
     if isinstance(ov, torch.Tensor):
         t = ov if ov.dtype == torch.uint8 else ov.clamp(0, 255).to(torch.uint8)
     else:
         a = np.asarray(ov)
         if a.dtype != np.uint8:
             a = np.clip(a, 0, 255).astype(np.uint8)
-        t = torch.from_numpy(np.ascontiguousarray(a))
+        t = torch.from_numpy(np.array(a, order="C"))      # own copy: the caller's array may be read-only
     if t.ndim != 3 or t.shape[2] != 4:
         raise ValueError(f"text_overlay_rgba must be H x W x 4, got {tuple(t.shape)}")
     if t.shape[0] != h or t.shape[1] != w:
-        raise NotImplementedError("text_overlay_rgba of a different size (PIL bilinear resize at ref:594/659) is not built")
+        from .text import fit_overlay
+        t = torch.from_numpy(np.array(fit_overlay(t.cpu().numpy(), h, w), order="C"))
     return t.to(device).contiguous()
 
 
@@ -413,9 +414,16 @@ def apply_crt_effect(
     blend = _lib.BLEND_NONE
     if state_prev is not None and persistence > 0.0:                       # ref:687
         prev = _as_device_tensor(state_prev, fr.device, torch.float32, None, "state_prev")
-        if tuple(prev.shape) != (h, w, 3):
-            raise NotImplementedError("state_prev of a different size (cv2.resize at ref:690) is not built yet")
-        state = prev.clone()      # the reference never mutates state_prev
+        if prev.ndim != 3 or prev.shape[2] != 3:
+            raise ValueError(f"state_prev must be H x W x 3, got {tuple(prev.shape)}")
+        if tuple(prev.shape) != (h, w, 3):                                 # ref:689-690: cv2.resize(state_prev, (w, h), INTER_LINEAR)
+            state = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)
+            with torch.cuda.device(fr.device):
+                rc = eng.lib.crtfx_resize_state(eng.ctx, prev.data_ptr(), int(prev.shape[0]), int(prev.shape[1]), state.data_ptr(),
+                                                _stream_ptr(fr.device))
+            _lib.check(eng.lib, eng.ctx, rc)
+        else:
+            state = prev.clone()      # the reference never mutates state_prev
         blend = _lib.BLEND_PREVIEW
     else:
         state = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)

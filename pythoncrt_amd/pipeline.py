@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib, tables
-from .effects import Engine, Settings, make_triad_mask, make_vignette
+from .effects import Engine, Settings, _overlay_tensor, make_triad_mask, make_vignette
 
 
 @dataclass
@@ -93,8 +93,11 @@ class FramePipeline:
     """One GPU's worth of the render loop."""
 
     def __init__(self, device: torch.device, h: int, w: int, settings: RenderSettings, fps: float = 30.0,
-                 noise_seed: int = 0, dtype: torch.dtype = torch.uint8):
+                 noise_seed: int = 0, dtype: torch.dtype = torch.uint8, text_overlay_rgba=None, text_overlay_after: bool = True):
         self.device, self.h, self.w, self.rs, self.fps = device, int(h), int(w), settings, float(fps)
+        # the one overlay plane of a render (ref:1076-1077: built once per frame there, identical every time)
+        self.overlay = _overlay_tensor(text_overlay_rgba, device, int(h), int(w)) if text_overlay_rgba is not None else None
+        self.overlay_after = bool(text_overlay_after)
         self.noise_seed = int(noise_seed)
         self.dtype = dtype                  # torch.uint8, or torch.float16 (half frames on the 0..255 scale)
         self.engine = Engine(device, h, w, _lib.PIX_F16 if dtype == torch.float16 else _lib.PIX_U8)
@@ -134,6 +137,8 @@ class FramePipeline:
             recs[j].flicker_factor = tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) if flick else 1.0  # ref:1064
             recs[j].noise_seed = self.noise_seed & 0xFFFFFFFFFFFFFFFF
             recs[j].frame_index = int(i)
+            if self.overlay is not None:
+                recs[j].overlay_rgba_dev, recs[j].overlay_after = self.overlay.data_ptr(), int(self.overlay_after)
             if noise_planes is not None:
                 recs[j].noise_plane_dev = noise_planes[j].data_ptr()
         if noise_planes is not None:

@@ -124,6 +124,47 @@ def dump_cli_fixture():
     json.dump(fixture, open(os.path.join(OUT, "reference_cli.json"), "w"), indent=1, sort_keys=True)
 
 
+TEXT_CASES = {       # name -> (w, h, text, font_family, size, color_hex, pos)
+    "default_font": (320, 96, "Hello CRT 0123", "", 36, "#FFCC00", (32, 32)),
+    "ttf_path": (256, 80, "AMD gfx950", "/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf", 28, "33aaff", (-6, 10)),
+    "unknown_family": (200, 64, "phosphor", "No Such Face", 20, "#zzzzzz", (4, 40)),
+    "empty": (40, 20, "", "", 36, "#FFFFFF", (32, 32)),
+}
+HEX_CASES = ["#FFCC00", "33aaff", " #010203 ", "#fff", "", "#zzzzzz", "12345", "#1234567"]
+
+
+def dump_text_fixture():
+    """The PIL text rasteriser (ref:350-414) and the size-mismatch resize of the overlay inside the
+    chain (ref:758-767): outputs of the reference's own function bodies on this image's Pillow."""
+    from PIL import Image, ImageDraw, ImageFont
+    tree = ast.parse(open(REF).read())
+    want = {"_parse_hex_color", "_make_text_overlay_rgba", "perf_add", "shift_channel", "apply_color_adjustments",
+            "make_scanline_mask_dynamic", "make_scanline_mask_2d", "_apply_triad_mask", "apply_barrel_warp", "apply_static_effects"}
+    nodes = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert want == {n.name for n in nodes}
+    ns = {"np": np, "os": os, "time": time, "cv2": RecordingCv2(), "Image": Image, "ImageDraw": ImageDraw, "ImageFont": ImageFont,
+          "Optional": Optional, "Tuple": Tuple, "_perf_lock": threading.Lock(), "_perf_totals": defaultdict(float),
+          "_perf_counts": defaultdict(int)}
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), "<reference functions>", "exec"), ns)
+    out = {}
+    for name, (w, h, text, fam, size, col, pos) in TEXT_CASES.items():
+        if fam.startswith("/") and not os.path.isfile(fam):
+            continue
+        out[f"text/{name}"] = ns["_make_text_overlay_rgba"](w, h, text, fam, size, col, pos)
+    out["hex"] = np.array([ns["_parse_hex_color"](c) for c in HEX_CASES], dtype=np.int64)
+    # overlay smaller than the frame, blended before and after an otherwise empty chain
+    ov = ns["_make_text_overlay_rgba"](64, 24, "ab", "", 36, "#80FF40", (2, 2))
+    rng = np.random.default_rng(77)
+    frame = rng.integers(0, 256, (36, 80, 3), dtype=np.uint8)
+    out["fit/overlay"], out["fit/frame"] = ov, frame
+    for after in (False, True):
+        out[f"fit/static_after{int(after)}"] = ns["apply_static_effects"](
+            frame, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0, 0.0,
+            text_overlay_rgba=ov, text_overlay_after=after)
+    np.savez_compressed(os.path.join(OUT, "reference_text_overlay.npz"), **out)
+    print(f"wrote {len(out)} text arrays")
+
+
 def frames(h, w):
     rng = np.random.default_rng(0)
     noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -262,6 +303,7 @@ def main():
     out["chain/48x64/noise/glitch_preview_float"] = c[1]
 
     dump_cli_fixture()
+    dump_text_fixture()
     np.savez_compressed(os.path.join(OUT, "reference_numpy_stages.npz"), **out)
     total = sum(v.nbytes for v in out.values())
     print(f"wrote {len(out)} arrays, {total/1e6:.2f} MB raw")

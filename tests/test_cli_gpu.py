@@ -1,0 +1,107 @@
+"""GPU, SURVEY 8f rows 1 and 4: the CLI end to end on raw rgb24 files (pinned double-buffered staging, batches
+that do not divide the clip, persistence carried across batches, the --text overlay), and an overlay whose
+size differs from the frame's against the reference's own outputs (tests/golden/reference_text_overlay.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import crt_oracle as orc  # noqa: E402  (checker only)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def pc():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    import pythoncrt_amd
+    return pythoncrt_amd
+
+
+def clip(n, h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255) // (w - 1), (yy * 255) // (h - 1), ((xx + yy) * 255) // (h + w - 2)], axis=2)
+    return np.stack([np.clip((base + 9 * i + rng.integers(0, 80, (h, w, 3))) // 2 + 30, 0, 255) for i in range(n)]).astype(np.uint8)
+
+
+def run_cli(pc, tmp_path, frames, extra, batch):
+    from pythoncrt_amd import cli
+    n, h, w = frames.shape[:3]
+    src, dst = tmp_path / "in.rgb", tmp_path / "out.rgb"
+    src.write_bytes(frames.tobytes() + b"\x01\x02\x03")          # a trailing partial frame is ignored
+    rc = cli.main(["--input", str(src), "--output", str(dst), "--width", str(w), "--height", str(h), "--fps", "30",
+                   "--batch", str(batch), "--noise-seed", "99"] + extra)
+    assert rc == 0
+    out = np.frombuffer(dst.read_bytes(), dtype=np.uint8)
+    assert out.size == n * h * w * 3
+    return out.reshape(n, h, w, 3)
+
+
+def test_cli_matches_pipeline_and_oracle(pc, tmp_path):
+    """Reference CLI defaults (fast bloom, pixel_size 2, persistence 0.2, triad softness 0.5) with the grain off
+    so that the oracle's process_frames can check the bytes; batch 3 over 8 frames = three batches, last short."""
+    from pythoncrt_amd import cli
+    from pythoncrt_amd.pipeline import FramePipeline
+    n, h, w = 8, 72, 128
+    frames = clip(n, h, w, 5)
+    extra = ["--noise-strength", "0", "--warp-strength", "0.15"]
+    out = run_cli(pc, tmp_path, frames, extra, batch=3)
+    a = cli.build_parser().parse_args(["--input", "x"] + extra)
+    rs = cli.settings_from_args(a)
+    # one-shot pipeline run: same bytes whatever the batching
+    dev = torch.device("cuda", 0)
+    pipe = FramePipeline(dev, h, w, rs, fps=30, noise_seed=99)
+    direct, _ = pipe.run(torch.from_numpy(frames).to(dev))
+    assert np.array_equal(out, direct.cpu().numpy())
+    # oracle (render loop ref:1037-1131)
+    exp, _ = orc.process_frames(list(frames), dict(rs.__dict__), 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
+                                rs.triad_softness, rs.vignette_strength)
+    exp = np.stack(exp)
+    d = np.abs(out.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+
+
+def test_cli_text_overlay_and_grain(pc, tmp_path):
+    """--text draws through Pillow and blends on the GPU; the grain is reproducible from --noise-seed."""
+    from pythoncrt_amd import cli, text
+    from pythoncrt_amd.pipeline import FramePipeline
+    n, h, w = 5, 64, 160
+    frames = clip(n, h, w, 6)
+    extra = ["--text", "CRT", "--text-size", "20", "--text-x", "8", "--text-y", "6", "--text-color", "#40FF80", "--no-fast-bloom",
+             "--pixel-size", "1", "--persistence", "0"]
+    out_before = run_cli(pc, tmp_path, frames, extra, batch=2)
+    out_again = run_cli(pc, tmp_path, frames, extra, batch=4)
+    assert np.array_equal(out_before, out_again)
+    out_after = run_cli(pc, tmp_path, frames, extra + ["--text-after"], batch=2)
+    plain = run_cli(pc, tmp_path, frames, extra[10:], batch=2)
+    ov = text.make_text_overlay_rgba(w, h, "CRT", "", 20, "#40FF80", (8, 6))
+    inked = ov[..., 3] > 0
+    assert inked.any()
+    # --text-after: pixels the overlay does not touch are the plain render's; fully opaque ones carry the ink colour
+    assert np.array_equal(out_after[:, ~inked], plain[:, ~inked])
+    solid = ov[..., 3] == 255
+    if solid.any():
+        assert np.array_equal(out_after[0][solid], ov[solid][:, :3])
+    assert not np.array_equal(out_before, out_after)
+    # against the pipeline called directly with the same overlay
+    a = cli.build_parser().parse_args(["--input", "x"] + extra)
+    pipe = FramePipeline(torch.device("cuda", 0), h, w, cli.settings_from_args(a), fps=30, noise_seed=99, text_overlay_rgba=ov,
+                         text_overlay_after=False)
+    direct, _ = pipe.run(torch.from_numpy(frames).cuda())
+    assert np.array_equal(out_before, direct.cpu().numpy())
+
+
+def test_overlay_of_another_size_matches_reference(pc):
+    tg = np.load(os.path.join(HERE, "golden", "reference_text_overlay.npz"))
+    ov, frame = tg["fit/overlay"], tg["fit/frame"]
+    for after in (False, True):
+        got = pc.apply_static_effects(frame, 0.0, None, 2.2, False, 0, 0.0, 0.0, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0,
+                                      text_overlay_rgba=ov, text_overlay_after=after)
+        exp = tg[f"fit/static_after{int(after)}"]
+        assert got.shape == exp.shape and np.array_equal(got, exp.astype(np.float32))

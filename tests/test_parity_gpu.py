@@ -304,8 +304,8 @@ def test_errors_are_loud(pc):
         pc.apply_static_effects(frame[:, :, :2], *a[1:])
     with pytest.raises(ValueError):
         pc.apply_static_effects(frame, 0.0, pc.make_triad_mask(10, 10, 0.3), *a[3:])
-    with pytest.raises(NotImplementedError):
-        pc.apply_static_effects(*a, text_overlay_rgba=np.zeros((10, 10, 4), np.uint8))       # needs PIL's resize (ref:594)
+    with pytest.raises(ValueError):
+        pc.apply_static_effects(*a, text_overlay_rgba=np.zeros((10, 10, 3), np.uint8))       # RGBA plane wanted
     with pytest.raises(Exception, match="radius"):
         pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                        # sigma 40 -> radius 120 > 64
 
@@ -622,3 +622,45 @@ def test_fp16_normalise_exhaustive(pc):
     small[small > 255] = 255
     g2, e2 = both_static(pc, small, dict(bloom_sigma=3.0, bloom_strength=0.25))
     assert_bit_exact(g2, e2)
+
+
+# ---- preview path: the previous state arrives with another size (ref:689-690, cv2.resize INTER_LINEAR) ----------
+
+@pytest.mark.parametrize("prev_hw", [(40, 56), (128, 192), (100, 75), (64, 200), (1, 1)])
+@pytest.mark.parametrize("promoted", [False, True])
+def test_state_prev_of_another_size(pc, prev_hw, promoted):
+    """The window was resized between two ticks: state_prev is bilinearly resampled to the new frame size.  With an
+    unpromoted chain the state is float32 on both sides and the result is bit-exact; with the vignette on the
+    reference's state is float64 (held rounded to float32 on the GPU): 4e-7 / 1 LSB."""
+    h, w = 64, 96
+    ph, pw = prev_hw
+    c = dict(BASE, scanline_strength=0.6, aberration_px=1, bloom_sigma=1.2, bloom_strength=0.25)
+    vs = 0.25 if promoted else None
+    mk = lambda mod, hh, ww: (mod.make_triad_mask(hh, ww, 0.35, 0.5), mod.make_vignette(hh, ww, vs) if vs else None)
+    f0, f1 = make_frame(ph, pw, seed=81, kind="grad"), make_frame(h, w, seed=82, kind="grad")
+    (tg0, vg0), (to0, vo0) = mk(pc, ph, pw), mk(orc, ph, pw)
+    (tg1, vg1), (to1, vo1) = mk(pc, h, w), mk(orc, h, w)
+    _, sg = pc.apply_crt_effect(*crt_args(f0, tg0, vg0, 0.5, None, 3.0, c))
+    _, so = orc.apply_crt_effect(*crt_args(f0, to0, vo0, 0.5, None, 3.0, c))
+    assert sg.shape == (ph, pw, 3) and np.array_equal(sg, so.astype(np.float32))
+    ug, sg1 = pc.apply_crt_effect(*crt_args(f1, tg1, vg1, 0.5, sg, 4.0, c))
+    uo, so1 = orc.apply_crt_effect(*crt_args(f1, to1, vo1, 0.5, so, 4.0, c))
+    assert sg1.shape == (h, w, 3) and sg1.dtype == np.float32
+    if not promoted:
+        assert so1.dtype == np.float32
+        assert np.array_equal(sg1, so1) and np.array_equal(ug, uo)
+    else:
+        assert so1.dtype == np.float64
+        assert np.abs(sg1.astype(np.float64) - so1).max() <= 4e-7
+        d = np.abs(ug.astype(np.int16) - uo.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    # the resize entry point alone, against the oracle's restatement of cv2.resize on the same float32 state
+    dev = torch.device("cuda", 0)
+    from pythoncrt_amd.effects import _engine
+    eng = _engine(dev, h, w)
+    dst = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    src = torch.from_numpy(sg).to(dev)
+    rc = eng.lib.crtfx_resize_state(eng.ctx, src.data_ptr(), ph, pw, dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    exp = orc.resize(sg.astype(np.float64) if promoted else sg, (w, h), "linear")
+    assert np.array_equal(dst.cpu().numpy(), exp.astype(np.float32))
