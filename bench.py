@@ -65,6 +65,22 @@ def cpu_baseline(rs, h, w, fps, n_frames, seed=1234):
     return n_frames / dt, dt
 
 
+def copy_ceiling(device):
+    """GB/s (read + write) of a 1 GiB device-to-device copy: the practical HBM ceiling on this box."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +192,11 @@ def main():
                 "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_launch": int(alg_launch),
                 "algorithmic_bytes_per_frame": alg_bytes_frame, "chain_ms_per_launch_group": round(group_ms, 4),
                 "dominant_kernel": dom,
+                # SURVEY 8d's second figure: fabric bytes the PMC passes counted (FETCH_SIZE + WRITE_SIZE, L2 <-> Infinity
+                # Cache/HBM) over the same kernel time, next to what a plain device copy reaches on this box
+                "hbm_achieved": round(traffic / (group_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "hbm_frac": round(traffic / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "copy_ceiling": copy_ceiling(device),
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
             }

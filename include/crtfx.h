@@ -169,7 +169,9 @@ int crtfx_halo_correct_quantise(crtfx_ctx* ctx, const float* local_dev, const fl
  * frames_base + i*frame_stride_bytes and written at out_base + i*out_stride_bytes; `frames` is
  * a HOST array of n per-frame records.  persistence > 0 threads state_inout_dev through the
  * run (blend RENDER; the first frame passes through when first_has_state == 0).
- * local_states_base (optional) receives every frame's float state at stride H*W*3 floats. */
+ * local_states_base (optional) receives every frame's float state at stride H*W*3 floats (frame i blends against
+ * state i-1 there and writes state i: no copy per frame; it must not overlap state_inout_dev, which receives the
+ * last state at the end). */
 int crtfx_process_batch(crtfx_ctx* ctx, const void* frames_base, size_t frame_stride_bytes,
                         void* out_base, size_t out_stride_bytes, int n, const crtfx_frame* frames,
                         float* state_inout_dev, double persistence, int first_has_state,

@@ -46,6 +46,7 @@ struct crtfx_ctx {
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
     bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
+    int point_tiles = 0;             // CRTFX_POINT_TILES=n: rows (wavefronts) per k_point block, 1..16 (0 = 16)
     bool force_runtime_flags = false; // CRTFX_FORCE_RUNTIME_FLAGS=1: never take a gate-folded instantiation (tests)
     std::string err;
     // profiling
@@ -271,9 +272,40 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
     }
 }
 
+template <uint32_t SF, int BLEND>
+void launch_point_lean2(crtfx_ctx* c, dim3 grid, dim3 block, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const KFrame& kf, const KOut& ko) {
+    if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_point_lean<SF, CRTFX_PIX_F16, BLEND>), grid, block, 0, s, e0, e1, c->kp, kf, ko); }
+    else { CRTFX_LAUNCH((k_point_lean<SF, CRTFX_PIX_U8, BLEND>), grid, block, 0, s, e0, e1, c->kp, kf, ko); }
+}
+void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3 block, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                       const KFrame& kf, const KOut& ko) {
+    if (pixelate) { if (render) launch_point_lean2<SF_FAST_PIX, CRTFX_BLEND_RENDER>(c, grid, block, s, e0, e1, kf, ko); else launch_point_lean2<SF_FAST_PIX, CRTFX_BLEND_NONE>(c, grid, block, s, e0, e1, kf, ko); }
+    else { if (render) launch_point_lean2<SF_FAST, CRTFX_BLEND_RENDER>(c, grid, block, s, e0, e1, kf, ko); else launch_point_lean2<SF_FAST, CRTFX_BLEND_NONE>(c, grid, block, s, e0, e1, kf, ko); }
+}
+
+template <bool PROMOTE, int BLEND>
+void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+}
+
 void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s) {
     ProfEv pe(c, 1, g);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
+    // plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend)
+    bool lean = !identity && !c->force_generic;
+    for (int j = 0; j < g && lean; ++j) {
+        const KOut& o = wg.o[j];
+        lean = !o.overlay_after && !o.glitch_offs && !o.out_f32 && o.blend == wg.o[0].blend &&
+               (o.blend == CRTFX_BLEND_NONE || o.blend == CRTFX_BLEND_RENDER);
+    }
+    if (lean) {
+        const bool prom = (c->kp.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
+        const bool rend = wg.o[0].blend == CRTFX_BLEND_RENDER;
+        if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, s, pe.e0, pe.e1); }
+        else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, s, pe.e0, pe.e1); }
+        return;
+    }
     CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, identity ? 1 : 0);
 }
 
@@ -312,8 +344,14 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
             hipLaunchKernelGGL(k_half, gh, dim3(256), 0, s, c->kp, kf);
         }
         ProfEv pe(c, 0);
-        dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
-        CRTFX_LAUNCH(k_point, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
+        const int waves = c->point_tiles > 0 ? c->point_tiles : 8;       // rows per block (CRTFX_POINT_TILES): 1080p 4 rows 34.8 us, 8 rows 32.9, 16 rows 37.5
+        dim3 grid((c->W + TW - 1) / TW, (c->H + waves - 1) / waves);
+        const uint32_t gates = fl & ~(uint32_t)CRTFX_F_WARP;
+        const bool lean = !c->force_generic && !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full &&
+                          !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane && !kf.overlay_before && c->kp.grain <= 1 &&
+                          !k1.overlay_after && !k1.out_f32 && (k1.blend == CRTFX_BLEND_NONE || k1.blend == CRTFX_BLEND_RENDER);
+        if (lean) launch_point_lean(c, gates == SF_FAST_PIX, k1.blend == CRTFX_BLEND_RENDER, grid, dim3(64 * waves), s, pe.e0, pe.e1, kf, k1);
+        else CRTFX_LAUNCH((k_point<SF_RUNTIME>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
     }
     if (two) {
         KWarpGroup wg{};
@@ -362,6 +400,7 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     }
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    if (const char* pt = getenv("CRTFX_POINT_TILES")) c->point_tiles = atoi(pt);
     const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
     c->force_runtime_flags = fr && fr[0] == '1';
     const char* dp = getenv("CRTFX_DBG_PTR");
@@ -579,17 +618,16 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         ko.pix = c->pix_fmt;
         ko.out_u8 = out_base ? static_cast<uint8_t*>(out_base) + (size_t)i * out_stride_bytes : nullptr;
         ko.p = persistence; ko.q = 1.0 - persistence;
-        if (blend_on) { ko.state = state_inout_dev; ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE; }
+        if (blend_on) {
+            ko.state = state_inout_dev; ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE;
+            if (local_states_base) {     // per-frame states wanted: frame i reads state i-1 and writes state i in place of a copy per frame
+                ko.state = local_states_base + (size_t)i * frame_elems;
+                ko.state_in = i ? local_states_base + (size_t)(i - 1) * frame_elems : state_inout_dev;
+            }
+        }
         return ko;
     };
     auto frame_in = [&](int i) { return static_cast<const uint8_t*>(frames_base) + (size_t)i * frame_stride_bytes; };
-    auto copy_state = [&](int i) -> int {
-        if (!local_states_base) return CRTFX_OK;
-        HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)i * frame_elems, state_inout_dev, frame_elems * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
-        return CRTFX_OK;
-    };
-
     int i = 0, group_no = 0;
     while (i < n) {
         // ---- grouped path: Gaussian-bloom chain on the register-window kernel, up to group_max frames per launch ----
@@ -632,9 +670,6 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                             KWarpGroup wg{};
                             wg.pre[0] = pre0 + (size_t)j * frame_elems; wg.o[0] = final_out(i + j);
                             launch_warp_group(c, wg, 1, !warp, sw);
-                            if (local_states_base)
-                                HIP_TRY(c, hipMemcpyAsync(local_states_base + (size_t)(i + j) * frame_elems, state_inout_dev,
-                                                          frame_elems * sizeof(float), hipMemcpyDeviceToDevice, sw));
                         }
                     }
                 }
@@ -648,13 +683,16 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         // ---- general path, one frame ------------------------------------------------------------------------
         int rc = run_chain(c, frame_in(i), frames ? &frames[i] : nullptr, final_out(i), s);
         if (rc) return rc;
-        if ((rc = copy_state(i))) return rc;
         ++i;
     }
+
     if (c->overlap) {      // everything issued on the side stream is ordered before whatever the caller enqueues next
         for (int k = 0; k < 2; ++k)
             if (c->ev_k2_pending[k]) { HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[k], 0)); c->ev_k2_pending[k] = false; }
     }
+    if (local_states_base && n > 0)      // the carried state = the last frame's
+        HIP_TRY(c, hipMemcpyAsync(state_inout_dev, local_states_base + (size_t)(n - 1) * frame_elems, frame_elems * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
     return CRTFX_OK;
 }
 

@@ -15,6 +15,7 @@
 //   k_point      the same chain with bloom off: purely pointwise, no LDS staging
 //   k_warp       a12 barrel-warp bilinear gather (+ a14 persistence, a15 quantise)
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "crtfx.h"
@@ -78,6 +79,7 @@ struct KOut {
     float* out_f32;      // final static float image or nullptr
     uint8_t* out_u8;     // quantised frame or nullptr
     float* state;        // persistence state in/out or nullptr
+    const float* state_in;   // previous state when it lives elsewhere than `state` (batch with per-frame states); nullptr = `state`
     int pix;             // crtfx_pixfmt of out_u8 (the quantised frame): uint8, or half = |x*255| unrounded
     int blend;           // crtfx_blend
     double p, q;         // persistence, 1 - persistence (double, as python computes them)
@@ -97,6 +99,8 @@ struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; };
 // internal gate (set by crtfx_set_params, never by callers): the analytic vignette gain lies in [0,1]
 // (0 <= strength <= 1), so clip(x * gain) of an x in [0,1] is the identity and is skipped.
 constexpr uint32_t KF_VIG_UNIT = 1u << 24;
+// the full-chain gate set of BASELINE configs 2-5 (everything but the bloom flavour, warp and pixelate)
+constexpr uint32_t SF_FULL_GATES = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE | KF_VIG_UNIT;
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
 constexpr int NB = 8;             // rows per H-pass block / register-blocked V outputs
@@ -127,7 +131,8 @@ __device__ __forceinline__ int wrap(int x, int W) {
 
 // a1+a2(+a3): one RGB sample of the aberrated (and pixelated) float image; (y, x) in range.
 // ref:569-584 — R'[x] = R[(x-d) mod W], B'[x] = B[(x+d) mod W]; pixelate = index maps.
-struct RawRGB { uint32_t r, g, b; };   // the three stored samples of a pixel: bytes, or half bit patterns
+struct RawRGB { uint32_t r, g, b; };
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };   // one RGB float pixel: a 12-byte, 4-aligned load   // the three stored samples of a pixel: bytes, or half bit patterns
 
 // a1 for either pixel format: uint8 -> u/255 (norm_u8); half -> float(h)/255 with a true division
 // (ref:569 `frame.astype(np.float32) / 255.0` applied to a float16 frame array).
@@ -404,11 +409,11 @@ __device__ __forceinline__ PackedPix commit_pixel(const KOut& O, uint32_t pix, T
     if constexpr (!BLEND) {
         // lean kernels: the host routes blended commits through k_commit / k_warp
     } else if (O.blend == CRTFX_BLEND_RENDER) {           // ref:1092
-        const float* s = O.state + pix * 3u;
+        const float* s = (O.state_in ? O.state_in : O.state) + pix * 3u;
         const T p = (T)O.p, q = (T)O.q;
         v0 = clip01(p * (T)s[0] + q * v0); v1 = clip01(p * (T)s[1] + q * v1); v2 = clip01(p * (T)s[2] + q * v2);
     } else if (O.blend == CRTFX_BLEND_PREVIEW) {   // ref:693 addWeighted = fma(prev, a, img*b)
-        const float* s = O.state + pix * 3u;
+        const float* s = (O.state_in ? O.state_in : O.state) + pix * 3u;
         const T p = (T)O.p, q = (T)O.q;
         if constexpr (sizeof(T) == 8) {
             v0 = fma((T)s[0], p, v0 * q); v1 = fma((T)s[1], p, v1 * q); v2 = fma((T)s[2], p, v2 * q);
@@ -497,8 +502,15 @@ __global__ __launch_bounds__(256) void k_half(KParams P, KFrame F) {
 
 // k_point — no Gaussian bloom: the chain is pointwise (plus, for fast bloom, a 2x2 gather from the
 // half-res image k_half left in P.ds).  One thread per pixel, 4 rows x 64 px per block.
-__global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
+// Block = 64 px x (blockDim.x / 64) rows; the host launches 1024 threads (16 rows) so that the two gamma LUTs
+// (8 KB) are staged into LDS once per 1024 pixels.  (A loop over row tiles inside a 256-thread block instead keeps
+// the whole kernel-argument block live across the loop: 101 SGPR spills, 88 VGPRs, 43 us instead of 34 at 1080p.)
+// SF: the gate word folded at compile time (see k_phosphor_rr), or SF_RUNTIME.
+template <uint32_t SF>
+__global__ __launch_bounds__(1024) void k_point(KParams Pin, KFrame F, KOut O) {
     __shared__ float lut[2 * LUT_STRIDE];
+    KParams P = Pin;
+    if constexpr (SF != 0xFFFFFFFFu) P.flags = SF;
     const bool use_lut = (P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT);
     if (use_lut) {
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
     }
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (y >= P.H) return;                      // whole wavefront exits together
     const int x = x0 + lane;
     const bool live = x < P.W;
@@ -530,6 +542,59 @@ __global__ __launch_bounds__(256) void k_point(KParams P, KFrame F, KOut O) {
         }
     }
     emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
+}
+
+// k_point_lean — k_point for a plain render frame: gate word, pixel format and blend mode are compile-time, no
+// per-pixel planes, overlays or float output (the host checks).  With every gate folded the body is one
+// basic block: the index-table loads, then the byte / half-res / mask / state loads issue together instead of one
+// memory round trip per stage (the general k_point waits at every branch that contains a load: ~5 dependent round
+// trips per wavefront made the 1080p reference-CLI-default chain latency-bound at 33 us).
+constexpr uint32_t SF_FAST = SF_FULL_GATES | CRTFX_F_BLOOM_FAST;
+constexpr uint32_t SF_FAST_PIX = SF_FAST | CRTFX_F_PIXELATE;
+template <uint32_t SF, int PIX, int BLENDM>
+__global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KOut Oin) {
+    __shared__ float lut[2 * LUT_STRIDE];
+    KParams P = Pin;
+    P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    KFrame F = Fin;
+    F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+    KOut O = Oin;
+    O.blend = BLENDM; O.overlay_after = nullptr; O.out_f32 = nullptr; O.pix = PIX;
+    if constexpr ((SF & CRTFX_F_TRIAD) && (SF & CRTFX_F_TRIAD_LUT)) {
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (y >= P.H) return;
+    const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+    const PixMasks M = load_masks(P, F, y, x);
+    float r, g, b;
+    fetch_graded(P, F, y, x, r, g, b);
+    if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
+        const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
+        const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
+        const float a1 = P.ux_a[x], a0 = 1.0f - a1, b1 = P.uy_a[y], b0 = 1.0f - b1;
+        const F3 p00 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx) * 3);
+        const F3 p01 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx1) * 3);
+        const F3 p10 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx) * 3);
+        const F3 p11 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx1) * 3);
+        const float bl0 = (p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1;
+        const float bl1 = (p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1;
+        const float bl2 = (p00.z * a0 + p01.z * a1) * b0 + (p10.z * a0 + p11.z * a1) * b1;
+        r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+    }
+    using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
+    T v0, v1, v2;
+    tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v0, v1, v2);
+    if (O.pre) {                                 // two-kernel path: park the pre-warp pixel for k_warp
+        *reinterpret_cast<F3*>(O.pre + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
+        return;
+    }
+    const PackedPix pk = commit_pixel<T, true>(O, pix, v0, v1, v2);
+    if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), pk);
 }
 #endif  // CRTFX_MAIN_TU
 
@@ -714,7 +779,7 @@ __host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix) { return N
 // 178 -> 144 us per 4K frame at equal source.  The host picks the instantiation whose SF equals
 // the launch's flags, else the runtime-flag one.
 constexpr uint32_t SF_RUNTIME = 0xFFFFFFFFu;
-constexpr uint32_t SF_FULL = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE | KF_VIG_UNIT;
+constexpr uint32_t SF_FULL = SF_FULL_GATES;
 
 // The gate-folded build sits right at the 128-VGPR boundary (127..129 depending on small edits):
 // one register over and it drops from 4 to 3 waves per SIMD, i.e. from 4 to 3 resident blocks per
@@ -998,7 +1063,6 @@ __device__ __forceinline__ void warp_coords(const KParams& P, int y, int x, int&
     fx = sx & 31; fy = sy & 31;
 }
 
-struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };   // one RGB float pixel: a 12-byte, 4-aligned load
 
 // The four taps are loaded unconditionally from CLAMPED addresses (always inside the image) as
 // 12-byte vectors, all four in flight together; a tap that lies outside the image is then
@@ -1072,6 +1136,44 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int ident
         }
     }
     if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), packed);
+}
+#endif  // CRTFX_MAIN_TU
+
+#ifdef CRTFX_MAIN_TU
+// k_warp_lean — k_warp for the frames of a plain render: warp on, no glitch band, no overlay, no float output,
+// blend NONE or RENDER.  Image dtype, blend mode and pixel format are compile-time, so the body is straight-line
+// code: the four tap loads issue back to back and nothing waits on a branch (the general k_warp carries
+// eight runtime paths; hipcc puts an s_waitcnt vmcnt(0) in front of every branch that contains a load).
+template <bool PROMOTE, int BLEND, int PIX>
+__global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
+    using T = typename std::conditional<PROMOTE, double, float>::type;
+    const float* __restrict__ pre = G.pre[blockIdx.z];
+    const KOut O = G.o[blockIdx.z];
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= P.H) return;
+    const int x = x0 + lane;
+    const bool live = x < P.W;
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)min(x, P.W - 1);
+    int ix, iy, fx, fy;
+    warp_coords(P, y, min(x, P.W - 1), ix, iy, fx, fy);
+    T v0, v1, v2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if constexpr (BLEND == CRTFX_BLEND_RENDER) { const F3 S = *reinterpret_cast<const F3*>((O.state_in ? O.state_in : O.state) + pix * 3u); s0 = S.x; s1 = S.y; s2 = S.z; }
+    warp_sample<T>(P, pre, ix, iy, fx, fy, v0, v1, v2);
+    if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
+        const T p = (T)O.p, q = (T)O.q;
+        v0 = clip01(p * (T)s0 + q * v0); v1 = clip01(p * (T)s1 + q * v1); v2 = clip01(p * (T)s2 + q * v2);
+    }
+    const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
+    if (O.state && live) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
+    if (!O.out_u8) return;
+    if constexpr (PIX == CRTFX_PIX_F16) {
+        store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
+    } else {
+        store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16));
+    }
 }
 #endif  // CRTFX_MAIN_TU
 

@@ -210,6 +210,13 @@ class GpuShardEngine:
         self.pipe.run(frames, first_index=first_index, state=state, out=self.out[:n], records=recs, local_states=self.local[:n])
         return self.local[:n], self.out[:n]
 
+    def sequential_scan(self, frames, first_index, state):
+        """world 1: the chunk continues from the true state of the previous one (None at the start of the clip)."""
+        n = frames.shape[0]
+        recs = self.records.pop(first_index, None)
+        out, state = self.pipe.run(frames, first_index=first_index, state=state, out=self.out[:n], records=recs)
+        return out, state
+
     def correct(self, local, carry, p, out):
         pipe = self.pipe
         stream = torch.cuda.current_stream(pipe.device).cuda_stream

@@ -102,10 +102,15 @@ class ShardedRender:
         first = c * sh.chunk
         if not has_frames:
             raise NotImplementedError("every rank must own a chunk in every round (pad the clip to world*chunk frames)")
+        w, r = sh.world, sh.rank
+        if w == 1 and p > 0.0 and hasattr(self.engine, "sequential_scan"):
+            # one rank owns consecutive chunks: carry the state itself (the reference's in-order loop, ref:1081-1105),
+            # no zero-state scan and no correction pass
+            out, self.carry_next_round = self.engine.sequential_scan(frames, first, None if c == 0 else self.carry_next_round)
+            return out
         local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
         if p <= 0.0:
             return out
-        w, r = sh.world, sh.rank
         n = frames.shape[0]
         final_local = local[n - 1]
         carry = None

@@ -379,6 +379,18 @@ def test_kernel_variants_agree(pc, monkeypatch):
             a = (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 2.0, 1.25, False, 1, 0, 0.0)
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3))
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3, warp_strength=0.15))
+        # the render loop (uint8 out, persistence state): lean k_point / k_warp builds against the general ones
+        from pythoncrt_amd.pipeline import FramePipeline, RenderSettings, baseline_config
+        dev = torch.device("cuda", torch.cuda.current_device())
+        clip4 = torch.from_numpy(np.stack([make_frame(h, w, seed=61 + i, kind="grad") for i in range(4)])).to(dev)
+        for rs in (RenderSettings(), RenderSettings(pixel_size=1, persistence=0.0), RenderSettings(warp_strength=0.2),
+                   baseline_config(2)[0], baseline_config(4)[0]):
+            pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
+            keep = torch.empty((4, h, w, 3), dtype=torch.float32, device=dev) if rs.persistence > 0 else None
+            o, st = pipe.run(clip4, first_index=2, local_states=keep)
+            res.append(o.cpu().numpy())
+            if st is not None:
+                res.append(st.cpu().numpy())
         outs[name] = res
     effects._tls.engines = {}
     for name in ("runtime_flags", "generic"):
@@ -415,6 +427,16 @@ def test_sharded_persistence_pieces_on_gpu():
     local0, out0 = eng.local_scan(frames[:B], first_index=0, clip_start=True)
     torch.cuda.synchronize()
     assert torch.equal(out0, seq_out[:B]) and torch.equal(local0, states[:B])
+    # one rank: ShardedRender carries the state itself from chunk to chunk — the in-order frames, bit for bit
+    from pythoncrt_amd.shard import FrameShard, ShardedRender
+    render = ShardedRender(FrameShard(1, 0, B), rs.persistence, GpuShardEngine(pipe, B), dist=None)
+    got = torch.cat([render.run_round(frames[r * B:(r + 1) * B], r).clone() for r in range(2)])
+    assert torch.equal(got, seq_out)
+    # the carried state is the last frame's, and the batch call leaves it in state_inout
+    st = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    keep = torch.empty((B, h, w, 3), dtype=torch.float32, device=dev)
+    _, st_out = pipe.run(frames[:B], first_index=0, state=None, local_states=keep)
+    assert torch.equal(st_out, keep[B - 1]) and torch.equal(keep, states[:B])
 
 
 # ---- pixelate, text overlay, glitch, grain size, fast bloom ----------------------------
