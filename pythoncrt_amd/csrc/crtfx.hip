@@ -46,6 +46,7 @@ struct crtfx_ctx {
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
     bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
+    int warp_rows = 2;               // CRTFX_WARP_ROWS=1|2: output rows per k_warp_lean thread
     int point_tiles = 0;             // CRTFX_POINT_TILES=n: rows (wavefronts) per k_point block, 1..16 (0 = 16)
     bool force_runtime_flags = false; // CRTFX_FORCE_RUNTIME_FLAGS=1: never take a gate-folded instantiation (tests)
     std::string err;
@@ -285,8 +286,17 @@ void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3
 
 template <bool PROMOTE, int BLEND>
 void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
-    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+    const int rows = c->warp_rows;      // output rows per thread
+    grid.y = (c->H + 4 * rows - 1) / (4 * rows);
+    if (c->pix_fmt == CRTFX_PIX_F16) {
+        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+    } else {
+        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+    }
 }
 
 void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s) {
@@ -341,7 +351,17 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     } else {
         if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
             dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4);
-            hipLaunchKernelGGL(k_half, gh, dim3(256), 0, s, c->kp, kf);
+            const uint32_t g0 = fl & ~(uint32_t)CRTFX_F_WARP;
+            const bool fold = !c->force_generic && !c->force_runtime_flags && (g0 == SF_FAST || g0 == SF_FAST_PIX) && !kf.overlay_before;
+            const bool f16 = c->pix_fmt == CRTFX_PIX_F16;
+            if (!fold) hipLaunchKernelGGL((k_half<SF_RUNTIME, 0>), gh, dim3(256), 0, s, c->kp, kf);
+            else if (g0 == SF_FAST_PIX) {
+                if (f16) hipLaunchKernelGGL((k_half<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kf);
+                else hipLaunchKernelGGL((k_half<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kf);
+            } else {
+                if (f16) hipLaunchKernelGGL((k_half<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kf);
+                else hipLaunchKernelGGL((k_half<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kf);
+            }
         }
         ProfEv pe(c, 0);
         const int waves = c->point_tiles > 0 ? c->point_tiles : 8;       // rows per block (CRTFX_POINT_TILES): 1080p 4 rows 34.8 us, 8 rows 32.9, 16 rows 37.5
@@ -401,6 +421,7 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     const char* fg = getenv("CRTFX_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     if (const char* pt = getenv("CRTFX_POINT_TILES")) c->point_tiles = atoi(pt);
+    if (const char* wr = getenv("CRTFX_WARP_ROWS")) { const int v = atoi(wr); c->warp_rows = (v == 1 || v == 4) ? v : 2; }
     const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
     c->force_runtime_flags = fr && fr[0] == '1';
     const char* dp = getenv("CRTFX_DBG_PTR");

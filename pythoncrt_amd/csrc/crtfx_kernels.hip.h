@@ -101,6 +101,9 @@ struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; };
 constexpr uint32_t KF_VIG_UNIT = 1u << 24;
 // the full-chain gate set of BASELINE configs 2-5 (everything but the bloom flavour, warp and pixelate)
 constexpr uint32_t SF_FULL_GATES = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT | CRTFX_F_SCANLINES | CRTFX_F_VIGNETTE | CRTFX_F_NOISE | KF_VIG_UNIT;
+// ... with the fast half-res bloom (the reference CLI's default), without / with pixelate
+constexpr uint32_t SF_FAST = SF_FULL_GATES | CRTFX_F_BLOOM_FAST;
+constexpr uint32_t SF_FAST_PIX = SF_FAST | CRTFX_F_PIXELATE;
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
 constexpr int NB = 8;             // rows per H-pass block / register-blocked V outputs
@@ -469,7 +472,13 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
 // k_half writes ds (graded + thresholded source at half resolution) into the ctx scratch P.ds:
 //   * exact 2x decimation (W, H even): OpenCV's INTER_AREA fast path, (p00 + p01 + p10 + p11) * 0.25;
 //   * otherwise the generic bilinear taps from the dx/dy axis tables.
-__global__ __launch_bounds__(256) void k_half(KParams P, KFrame F) {
+// SF / PIX: gate word and pixel format folded at compile time for a plain render frame (see k_point_lean), or
+// SF = 0xFFFFFFFF for the general build.
+template <uint32_t SF, int PIX>
+__global__ __launch_bounds__(256) void k_half(KParams Pin, KFrame Fin) {
+    KParams P = Pin;
+    KFrame F = Fin;
+    if constexpr (SF != 0xFFFFFFFFu) { P.flags = SF; P.pix = PIX; F.overlay_before = nullptr; }
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= P.hw || j >= P.hh) return;
@@ -549,8 +558,6 @@ __global__ __launch_bounds__(1024) void k_point(KParams Pin, KFrame F, KOut O) {
 // basic block: the index-table loads, then the byte / half-res / mask / state loads issue together instead of one
 // memory round trip per stage (the general k_point waits at every branch that contains a load: ~5 dependent round
 // trips per wavefront made the 1080p reference-CLI-default chain latency-bound at 33 us).
-constexpr uint32_t SF_FAST = SF_FULL_GATES | CRTFX_F_BLOOM_FAST;
-constexpr uint32_t SF_FAST_PIX = SF_FAST | CRTFX_F_PIXELATE;
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KOut Oin) {
     __shared__ float lut[2 * LUT_STRIDE];
@@ -1144,35 +1151,74 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int ident
 // blend NONE or RENDER.  Image dtype, blend mode and pixel format are compile-time, so the body is straight-line
 // code: the four tap loads issue back to back and nothing waits on a branch (the general k_warp carries
 // eight runtime paths; hipcc puts an s_waitcnt vmcnt(0) in front of every branch that contains a load).
-template <bool PROMOTE, int BLEND, int PIX>
+// ROWS output rows per thread (y, y + 4, ...): the gathers of all of them are issued before the first is used.
+struct WarpTaps { F3 A, B, C, D; float u00, u01, u10, u11; };
+__device__ __forceinline__ WarpTaps warp_load(const KParams& P, const float* __restrict__ pre, int ix, int iy, int fx, int fy) {
+    WarpTaps t;
+    const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
+    const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
+    const bool xin0 = (unsigned)ix < (unsigned)P.W, xin1 = (unsigned)(ix + 1) < (unsigned)P.W;
+    const bool yin0 = (unsigned)iy < (unsigned)P.H, yin1 = (unsigned)(iy + 1) < (unsigned)P.H;
+    const int xa = min(max(ix, 0), P.W - 1), xb = min(max(ix + 1, 0), P.W - 1);
+    const int ya = min(max(iy, 0), P.H - 1), yb = min(max(iy + 1, 0), P.H - 1);
+    const uint32_t rowa = (uint32_t)ya * (uint32_t)P.W, rowb = (uint32_t)yb * (uint32_t)P.W;
+    t.A = *reinterpret_cast<const F3*>(pre + (rowa + (uint32_t)xa) * 3u);
+    t.B = *reinterpret_cast<const F3*>(pre + (rowa + (uint32_t)xb) * 3u);
+    t.C = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xa) * 3u);
+    t.D = *reinterpret_cast<const F3*>(pre + (rowb + (uint32_t)xb) * 3u);
+    t.u00 = (xin0 && yin0) ? wy0 * wx0 : 0.0f; t.u01 = (xin1 && yin0) ? wy0 * wx1 : 0.0f;      // see warp_sample
+    t.u10 = (xin0 && yin1) ? wy1 * wx0 : 0.0f; t.u11 = (xin1 && yin1) ? wy1 * wx1 : 0.0f;
+    return t;
+}
+template <typename T>
+__device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T& o2) {
+    o0 = (((T)t.A.x * (T)t.u00 + (T)t.B.x * (T)t.u01) + (T)t.C.x * (T)t.u10) + (T)t.D.x * (T)t.u11;
+    o1 = (((T)t.A.y * (T)t.u00 + (T)t.B.y * (T)t.u01) + (T)t.C.y * (T)t.u10) + (T)t.D.y * (T)t.u11;
+    o2 = (((T)t.A.z * (T)t.u00 + (T)t.B.z * (T)t.u01) + (T)t.C.z * (T)t.u10) + (T)t.D.z * (T)t.u11;
+}
+
+template <bool PROMOTE, int BLEND, int PIX, int ROWS>
 __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const float* __restrict__ pre = G.pre[blockIdx.z];
     const KOut O = G.o[blockIdx.z];
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= P.H) return;
-    const int x = x0 + lane;
-    const bool live = x < P.W;
-    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)min(x, P.W - 1);
-    int ix, iy, fx, fy;
-    warp_coords(P, y, min(x, P.W - 1), ix, iy, fx, fy);
-    T v0, v1, v2;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if constexpr (BLEND == CRTFX_BLEND_RENDER) { const F3 S = *reinterpret_cast<const F3*>((O.state_in ? O.state_in : O.state) + pix * 3u); s0 = S.x; s1 = S.y; s2 = S.z; }
-    warp_sample<T>(P, pre, ix, iy, fx, fy, v0, v1, v2);
-    if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
-        const T p = (T)O.p, q = (T)O.q;
-        v0 = clip01(p * (T)s0 + q * v0); v1 = clip01(p * (T)s1 + q * v1); v2 = clip01(p * (T)s2 + q * v2);
+    const int ybase = blockIdx.y * (4 * ROWS) + (threadIdx.x >> 6);
+    if (ybase >= P.H) return;
+    const int x = min(x0 + lane, P.W - 1);
+    const bool live = x0 + lane < P.W;
+    const float* state_in = O.state_in ? O.state_in : O.state;
+    WarpTaps taps[ROWS];
+    F3 st[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = min(ybase + 4 * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
+        int ix, iy, fx, fy;
+        warp_coords(P, y, x, ix, iy, fx, fy);
+        taps[r] = warp_load(P, pre, ix, iy, fx, fy);
+        if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
-    const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
-    if (O.state && live) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
-    if (!O.out_u8) return;
-    if constexpr (PIX == CRTFX_PIX_F16) {
-        store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
-    } else {
-        store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16));
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = ybase + 4 * r;
+        if (y >= P.H) break;                                  // wave-uniform
+        const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+        T v0, v1, v2;
+        warp_combine<T>(taps[r], v0, v1, v2);
+        if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
+            const T p = (T)O.p, q = (T)O.q;
+            v0 = clip01(p * (T)st[r].x + q * v0); v1 = clip01(p * (T)st[r].y + q * v1); v2 = clip01(p * (T)st[r].z + q * v2);
+        }
+        const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
+        if (O.state && live) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
+        if (O.out_u8) {
+            if constexpr (PIX == CRTFX_PIX_F16) {
+                store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
+            } else {
+                store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16));
+            }
+        }
     }
 }
 #endif  // CRTFX_MAIN_TU
