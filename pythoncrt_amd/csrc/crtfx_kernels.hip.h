@@ -901,11 +901,15 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             const int j = it / SWP;
             if (j < nrows) {
                 const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
-                const uint32_t ro = (uint32_t)y * row_bytes;          // < 2^32 for any frame the ctx accepts
+                const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_bytes);   // y, row_bytes < 2^24 and the product < 2^32 for any frame the ctx accepts (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate)
                 raw[u] = load_raw(PIX, F.in, ro + offr[u], ro + offg[u], ro + offb[u]);
             }
         }
     };
+    // centre-ring row of the first row of the block being graded (A) / of the block being finished (C2): both advance
+    // by NB per iteration modulo CR (wave-uniform; replaces a division by CR per item and per row)
+    int crow0 = 0;                 // (hb - (y_begin - R)) % CR
+    int c2row0 = NB;               // (hb - NB - y_begin) % CR = CR - R - NB at the first iteration: image row of output row hb - NB - R
     // C2 of the block whose first H-row is hbp: output rows [hbp - R, hbp - R + NB) from tile `ht`
     auto phase_c2 = [&](int hbp, const float* ht) {
         const int x = x0 + lane;
@@ -917,7 +921,9 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
                 float r = 0, g = 0, b = 0;
                 PixMasks M{cm0, cm1, cm2, 1.0f, 1.0};
                 if (xin) {
-                    const uint32_t* cp = cring + (((y - (y_begin - R)) % CR) * TW + lane) * CRW;
+                    int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
+                    cr = cr >= CR ? cr - CR : cr;
+                    const uint32_t* cp = cring + (cr * TW + lane) * CRW;
                     uint32_t s0, s1, s2;
                     if constexpr (PIX) { const uint32_t lo = cp[0]; s0 = lo & 0xFFFFu; s1 = lo >> 16; s2 = cp[1]; }
                     else { const uint32_t pk = cp[0]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
@@ -942,7 +948,8 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     // in-order queue, so a wait placed right behind the stores would expose their latency.
     prefetch(y_begin - R);
     int t = 0;
-    for (int hb = y_begin - R; hb < y_end + R; hb += NB, t ^= 1) {
+    for (int hb = y_begin - R; hb < y_end + R; hb += NB, t ^= 1, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
+                                                   c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
         const int nrows = min(NB, y_end + R - hb);
         float* ht = hrow + t * HT;
         // ---- C1(n-1): vertical pass on the register window; row j = blur of output row hb-NB-R+j ----
@@ -975,7 +982,9 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
             const int j = it / SWP, i = it - j * SWP;
             if (j < nrows) {
                 if (i >= pad && i < pad + TW) {     // centre column: park the packed samples for C2
-                    uint32_t* cp = cring + (((hb + j - (y_begin - R)) % CR) * TW + (i - pad)) * CRW;
+                    int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division
+                    cr = cr >= CR ? cr - CR : cr;
+                    uint32_t* cp = cring + (cr * TW + (i - pad)) * CRW;
                     if constexpr (PIX) { cp[0] = raw[u].r | (raw[u].g << 16); cp[1] = raw[u].b; }
                     else cp[0] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
                 }
