@@ -686,3 +686,49 @@ def test_state_prev_of_another_size(pc, prev_hw, promoted):
     assert rc == 0
     exp = orc.resize(sg.astype(np.float64) if promoted else sg, (w, h), "linear")
     assert np.array_equal(dst.cpu().numpy(), exp.astype(np.float32))
+
+
+# ---- the reference's frame-parallel dispatcher shape (a16, ref:1015-1131) over the drop-in -------------------
+
+def test_two_worker_threads_like_process_video(pc):
+    """process_video calls apply_static_effects from a 2-thread pool (17 positional arguments, the rest by keyword,
+    ref:1045-1078) with shared read-only masks, keeps <= 4*workers futures in flight and commits strictly in
+    order.  The drop-in keeps one ctx per (device, size, thread): results must not depend on which thread ran a
+    frame, and the in-order commit must reproduce the single-threaded render."""
+    from concurrent.futures import ThreadPoolExecutor
+    h, w, n = 90, 160, 12
+    frames = [make_frame(h, w, seed=90 + i, kind="grad") for i in range(n)]
+    tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    fps, speed, p = 30.0, 30.0, 0.4
+
+    def job(i, f):
+        return pc.apply_static_effects(f, 0.6, tm, 2.2, False, 1, 1.2, 0.25, 0.0, 1.5, vg, 2.0, (i / fps) * speed, False, 1, 0, 0.0,
+                                       time_sec=i / fps, flicker_strength=0.3, flicker_hz=7.0, warp_strength=0.15,
+                                       noise_seed=5, frame_index=i)
+
+    def commit(results):
+        prev, outs = None, []
+        for i in range(n):
+            prev, u8 = orc.persistence_blend(prev, results[i], p)      # ref:1086-1098 (numpy blend + convertScaleAbs)
+            outs.append(u8)
+        return np.stack(outs)
+
+    single = {i: job(i, frames[i]) for i in range(n)}
+    workers, queue_cap = 2, 8
+    futures, got, nxt = {}, {}, 0
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for i, f in enumerate(frames):
+            futures[i] = ex.submit(job, i, f)
+            while len(futures) >= queue_cap or nxt in futures:
+                if nxt in futures:
+                    got[nxt] = futures.pop(nxt).result()
+                    nxt += 1
+                else:
+                    break
+        while nxt in futures:
+            got[nxt] = futures.pop(nxt).result()
+            nxt += 1
+    assert sorted(got) == list(range(n))
+    for i in range(n):
+        assert got[i].dtype == np.float32 and np.array_equal(got[i], single[i]), i
+    assert np.array_equal(commit(got), commit(single))
