@@ -1,0 +1,70 @@
+"""GPU: a seeded random sweep of the render loop (FramePipeline = crtfx_process_batch, in-kernel grain RNG, so the
+gate-folded / lean kernels are the ones that run) against the oracle's in-order render, over ragged frame sizes
+(narrower than a 64-px strip, shorter than an 8-row block, odd widths) and the whole settings space of the CLI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import crt_oracle as orc  # noqa: E402  (checker only)
+
+
+def draw_settings(rng):
+    from pythoncrt_amd.pipeline import RenderSettings
+    pick = lambda *a: a[int(rng.integers(len(a)))]
+    fast = bool(rng.integers(2))
+    return RenderSettings(
+        scanline_strength=pick(0.0, 0.6, 1.0), triad_strength=pick(0.0, 0.35, 0.9), triad_gamma=pick(2.2, 1.0, 0.7),
+        triad_preserve_luma=bool(rng.integers(2)), triad_softness=pick(0.0, 0.5, 1.4), aberration_px=int(pick(-8, -1, 0, 1, 3)),
+        bloom_sigma=pick(0.0, 0.5, 1.2, 3.0, 4.4), bloom_strength=pick(0.0, 0.25, 0.8), bloom_threshold=pick(0.0, 0.0, 0.3),
+        noise_strength=pick(0.0, 1.5, 6.0), vignette_strength=pick(0.0, 0.25, 1.0), persistence=pick(0.0, 0.2, 0.9),
+        scanline_speed_px_s=pick(30.0, 0.0, -12.5), scanline_period_px=pick(2.0, 3.7), fast_bloom=fast, pixel_size=int(pick(1, 1, 2, 3)),
+        brightness=pick(0.0, 0.0, 0.08), contrast=pick(1.0, 1.0, 1.25), gamma=1.0, saturation=pick(1.0, 1.0, 1.4), temperature=pick(0.0, 0.0, -0.5),
+        flicker_strength=pick(0.0, 0.0, 0.5), flicker_hz=pick(0.0, 9.0), grain_size=int(pick(1, 1, 1, 2)),
+        scanline_angle=pick(0.0, 0.0, 0.0, 12.0), scanline_thickness=pick(1.0, 1.0, 1.0, 2.0), warp_strength=pick(0.0, 0.15, 0.15, -0.3, 0.6),
+        glitch_amp_px=int(pick(0, 0, 0, 7)), glitch_height_frac=pick(0.0, 0.3))
+
+
+SIZES = [(1, 1), (2, 3), (7, 65), (9, 200), (33, 63), (64, 64), (37, 129), (90, 160), (17, 300), (130, 70)]
+
+
+@pytest.mark.parametrize("case", range(150))
+def test_random_render_matches_oracle(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from pythoncrt_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(1000 + case)
+    h, w = SIZES[case % len(SIZES)]
+    rs = draw_settings(rng)
+    n, first, fps, seed = 4, int(rng.integers(0, 50)), 25.0, int(rng.integers(1 << 40))
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    # the grain the kernels drew, exported for the oracle (cv2.randn is unreproducible)
+    gh, gw = (h, w) if rs.grain_size <= 1 else (max(1, h // rs.grain_size), max(1, w // rs.grain_size))
+    planes = None
+    if rs.noise_strength > 0.0:
+        planes = []
+        from pythoncrt_amd.effects import Engine
+        small = Engine(dev, gh, gw, 0) if (gh, gw) != (h, w) else pipe.engine
+        for i in range(n):
+            p = torch.empty((gh, gw), dtype=torch.float32, device=dev)
+            rc = small.lib.crtfx_noise_plane(small.ctx, seed, first + i, p.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            planes.append(p.cpu().numpy())
+    params = {k: getattr(rs, k) for k in (
+        "scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength", "bloom_threshold",
+        "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "glitch_amp_px", "glitch_height_frac", "brightness", "contrast",
+        "gamma", "saturation", "temperature", "flicker_strength", "flicker_hz", "grain_size", "scanline_angle", "scanline_thickness",
+        "warp_strength")}
+    exp, exp_state = orc.process_frames(list(frames), params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
+                                        rs.triad_softness, rs.vignette_strength, noise_planes=planes, first_index=first)
+    got = out.cpu().numpy()
+    d = np.abs(got.astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1, (case, rs, int(d.max()))
+    assert (d != 0).mean() <= max(2e-3, 2.0 / d.size), (case, rs, float((d != 0).mean()))
+    if rs.persistence > 0.0:
+        assert state is not None and np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6
