@@ -775,10 +775,12 @@ __host__ __device__ constexpr int rr_pad(int R) { return (R + 3) & ~3; }
 __host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
 // staging row stride in floats: a multiple of 64 dwords, so the channel planes a ds_read_b128 lane
 // group straddles start on the same bank and its 16-byte slots stay disjoint (stride 88 cost ~2x).
-__host__ __device__ constexpr int rr_sws(int R) { return (rr_swp(R) + 63) & ~63; }
+// Half frames take a 32-dword multiple instead (96 for every radius) and park their centre pixels as three 16-bit
+// planes: 45.9 -> 39.6 KB of LDS per block, i.e. 4 resident blocks per CU like the uint8 build instead of 3.
+__host__ __device__ constexpr int rr_sws(int R, int pix = 0) { return pix ? (rr_swp(R) + 31) & ~31 : (rr_swp(R) + 63) & ~63; }
 __host__ __device__ constexpr int rr_cring(int R) { return R + 2 * NB; }   // exact: LDS is what caps blocks per CU
 // LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
-__host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix) { return NB * 3 * rr_sws(R) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring(R) * TW * (pix ? 2 : 1); }
+__host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix) { return NB * 3 * rr_sws(R, pix) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + (pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW); }
 
 // SF: the stage gates (crtfx_params.flags without CRTFX_F_WARP, which k_phosphor never reads) as a
 // compile-time constant, or SF_RUNTIME.  With the gates folded the dead stages, their parameters
@@ -801,7 +803,6 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     if constexpr (SF != SF_RUNTIME) P.flags = SF;
     P.pix = PIX;
     O.pix = PIX;
-    constexpr int CRW = PIX ? 2 : 1;            // dwords per parked centre pixel
     // declared as float4 so that the 16-byte alignment of the dynamic LDS base is part of the type:
     // with a float[] base hipcc splits every 16-byte LDS access into ds_read2_b32/_b64 pairs, which
     // at a 16-byte lane stride are 4-way / 2-way bank conflicts (ds_read_b128 is conflict-free).
@@ -810,7 +811,7 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     constexpr int R = RT, K = 2 * R + 1;
     constexpr int pad = rr_pad(R);
     constexpr int SWP = rr_swp(R);
-    constexpr int SWS = rr_sws(R);
+    constexpr int SWS = rr_sws(R, PIX);
     constexpr int L = 2 * R + NB;               // register window length
     constexpr int CR = rr_cring(R);             // centre ring rows: R + 2 NB
     constexpr int A_ITEMS = (NB * SWP + RR_THREADS - 1) / RR_THREADS;
@@ -819,8 +820,9 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
     float* stg = smem;                          // [NB][3][SWS] (SWP used)
     float* hrow = stg + NB * 3 * SWS;           // [2][NB][3][TW]  H-pass rows, then blur rows in place
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
-    uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // [CR][TW] packed centre pixels
-    uint32_t* rowtab = cring + CR * TW * CRW;                              // [16][3] ring: scan gain bits, ny2 lo, ny2 hi of output row y at (y - y_begin) & 15
+    uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // uint8: [CR][TW] packed r|g<<8|b<<16.  half: [CR][3][TW] uint16 planes
+    uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
+    uint32_t* rowtab = cring + (PIX ? (CR * TW * 3 + 1) / 2 : CR * TW);                              // [16][3] ring: scan gain bits, ny2 lo, ny2 hi of output row y at (y - y_begin) & 15
     int* ytab = reinterpret_cast<int*>(rowtab + 16 * 3);                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
@@ -923,10 +925,9 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
                 if (xin) {
                     int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;
-                    const uint32_t* cp = cring + (cr * TW + lane) * CRW;
                     uint32_t s0, s1, s2;
-                    if constexpr (PIX) { const uint32_t lo = cp[0]; s0 = lo & 0xFFFFu; s1 = lo >> 16; s2 = cp[1]; }
-                    else { const uint32_t pk = cp[0]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
+                    if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
+                    else { const uint32_t pk = cring[cr * TW + lane]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
                     const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 3;
                     M.sl = __uint_as_float(rt[0]);
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
@@ -984,9 +985,8 @@ __global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES
                 if (i >= pad && i < pad + TW) {     // centre column: park the packed samples for C2
                     int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;
-                    uint32_t* cp = cring + (cr * TW + (i - pad)) * CRW;
-                    if constexpr (PIX) { cp[0] = raw[u].r | (raw[u].g << 16); cp[1] = raw[u].b; }
-                    else cp[0] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
+                    if constexpr (PIX) { uint16_t* cp = cring16 + cr * 3 * TW + (i - pad); cp[0] = (uint16_t)raw[u].r; cp[TW] = (uint16_t)raw[u].g; cp[2 * TW] = (uint16_t)raw[u].b; }
+                    else cring[cr * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
                 }
                 float r = norm_px(PIX, raw[u].r), g = norm_px(PIX, raw[u].g), b = norm_px(PIX, raw[u].b);
                 grade(P, r, g, b);
