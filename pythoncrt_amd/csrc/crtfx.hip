@@ -184,11 +184,13 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
 // measured landscape (4K, R = 9: g=1/seg=128 -> 19 it/frame = 89 us; g=2/seg=256 -> 17.5 = 82.5 us, the short
 // last-segment blocks freeing slots for the overflow; g=2/seg=240 -> two full rounds = 103 us).
 struct GridPlan { int g, seg; };
-GridPlan plan_grid(int H, int W, int R, int pix, int gmin, int gmax_allowed) {
+GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax_allowed) {
     const int strips = (W + TW - 1) / TW;
-    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
+    const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
+    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix);
     int bpc = (int)(163840 / lds);
-    bpc = bpc > 4 ? 4 : (bpc < 1 ? 1 : bpc);
+    const int by_regs = rr_min_waves(Rk, folded || pix == CRTFX_PIX_F16);      // a block = one wave per SIMD
+    bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
     const int slots = bpc * 256;
     const int hcap = ((H + NB - 1) / NB) * NB;
     GridPlan best{1, hcap < 128 ? hcap : 128};
@@ -246,15 +248,15 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
 void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
-    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr, rr_launch_1, rr_launch_2, rr_launch_3, rr_launch_4,
-                                                          rr_launch_5, rr_launch_6, rr_launch_7, rr_launch_8, rr_launch_9,
-                                                          rr_launch_10, rr_launch_11, rr_launch_12};
+#define CRTFX_RR_ENTRY(r) , rr_launch_##r
+    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr CRTFX_RR_RADII(CRTFX_RR_ENTRY)};
+#undef CRTFX_RR_ENTRY
     const int R = c->kp.R;
-    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, g, g).seg;   // partial last group / single frames: planned once
+    const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, g, g).seg;   // partial last group / single frames: planned once
     const int seg = c->seg_for[g];
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
     const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
     ProfEv pe(c, 0, g);
     table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt),
@@ -534,7 +536,8 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         // 4K with 4 frames per grid = 398 MB and k_warp goes from 38 to 44 us per frame)
         int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
-        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, 1, gcap);
+        const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, 1, gcap);
         if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) { gp.g = v; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, v); } }
         if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) gp.seg = ((v + NB - 1) / NB) * NB; }
         const int need = c->overlap ? 2 * gp.g : gp.g;

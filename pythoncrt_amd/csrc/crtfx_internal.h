@@ -7,16 +7,17 @@
 namespace crtfx {
 
 // One per radius, each in its own translation unit (crtfx_rr.hip compiled with -DRR_R=n) so the
-// twelve sets of instantiations build in parallel.  variant: 0 = runtime gates (uint8), 1 = SF_FULL gates folded (uint8), 2 = SF_FULL + half frames.
+// thirty sets of instantiations build in parallel.  variant: 0 = runtime gates (uint8), 1 = SF_FULL gates folded (uint8), 2 = SF_FULL + half frames.
 using rr_launch_fn = void (*)(const KParams&, const KGroup&, int seg_rows, dim3 grid, size_t lds, hipStream_t, int variant,
                               hipEvent_t ev_start, hipEvent_t ev_stop);
 
+#define CRTFX_RR_RADII(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) \
+                          X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
 #define CRTFX_RR_DECL(r) void rr_launch_##r(const KParams&, const KGroup&, int, dim3, size_t, hipStream_t, int, hipEvent_t, hipEvent_t);
-CRTFX_RR_DECL(1) CRTFX_RR_DECL(2) CRTFX_RR_DECL(3) CRTFX_RR_DECL(4) CRTFX_RR_DECL(5) CRTFX_RR_DECL(6)
-CRTFX_RR_DECL(7) CRTFX_RR_DECL(8) CRTFX_RR_DECL(9) CRTFX_RR_DECL(10) CRTFX_RR_DECL(11) CRTFX_RR_DECL(12)
+CRTFX_RR_RADII(CRTFX_RR_DECL)
 #undef CRTFX_RR_DECL
 
-constexpr int RR_MAX_RADIUS = 12;
+constexpr int RR_MAX_RADIUS = 30;      // bloom sigma <= 10 (the reference GUI's range, ref:1475); larger radii take the LDS-ring kernel
 
 // Launch with optional timing events attached to the dispatch packet itself (hipExtLaunchKernelGGL):
 // no extra packets on the stream.  Separate hipEventRecord calls around every kernel cost ~5 us of

@@ -795,8 +795,13 @@ constexpr uint32_t SF_FULL = SF_FULL_GATES;
 // CU and a second, partial round of blocks (+22 % time).  It is therefore pinned to 4 waves/SIMD;
 // the runtime-flag build needs ~147 VGPRs and would spill under that cap.
 // PIX: pixel format of the frames (folded like the gates); half frames park 2 dwords per centre pixel.
+// Radii 13..30 (bloom sigma up to 10, the reference GUI's range): the register window (2R + 8 values) no longer
+// fits 128 VGPRs, so those builds run 3 (R <= 20) or 2 resident blocks per CU.
+__host__ __device__ constexpr int rr_min_waves(int R, bool folded) {
+    return R <= 12 ? (folded ? 4 : CRTFX_RR_WAVES) : (R <= 20 ? (folded ? 3 : 2) : 2);
+}
 template <int RT, uint32_t SF, int PIX = 0>
-__global__ __launch_bounds__(RR_THREADS, (SF != 0xFFFFFFFFu ? 4 : CRTFX_RR_WAVES)) void k_phosphor_rr(KParams Pin, KGroup G, int seg_rows) {
+__global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) void k_phosphor_rr(KParams Pin, KGroup G, int seg_rows) {
     const KFrame F = G.f[blockIdx.z];
     KOut O = G.o[blockIdx.z];
     KParams P = Pin;

@@ -3,7 +3,7 @@
 #include "crtfx_internal.h"
 
 #ifndef RR_R
-#error "compile with -DRR_R=<radius 1..12>"
+#error "compile with -DRR_R=<radius 1..30>"
 #endif
 
 namespace crtfx {

@@ -150,7 +150,7 @@ def test_scanlines_2d_and_vignette_array(pc):
 
 
 @pytest.mark.parametrize("hw", SIZES + [(150, 64)])
-@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 6.5])
+@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 4.4, 6.5, 8.3, 10.0, 12.0])       # radii 9 4 2 1 12 | 13 20 25 30 (register window) | 36 (LDS ring)
 def test_bloom_bit_exact(pc, hw, sigma):
     """a5: separable Gaussian (LDS strips, ring H-pass, register-blocked V-pass) — same fmaf
     accumulation order as the oracle, so equal to the last bit, borders included."""
@@ -375,7 +375,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
             monkeypatch.setenv(k, v)
         effects._tls.engines = {}          # the switches are read when a ctx is created
         res = []
-        for sigma in (3.0, 1.2, 2.0):
+        for sigma in (3.0, 1.2, 2.0, 5.0, 10.0):
             a = (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 2.0, 1.25, False, 1, 0, 0.0)
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3))
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3, warp_strength=0.15))

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Frames/s of the 4K (or --h/--w) full chain as a function of the bloom sigma (radius = round(3 sigma)):
+shows where the register-window kernel (radius <= 12) hands over to the general LDS-ring kernel."""
+import argparse, dataclasses, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sigmas", type=float, nargs="+", default=[1.2, 3.0, 4.0, 4.5, 6.5, 10.0])
+ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
+ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+frames = torch.randint(0, 256, (a.batch, a.h, a.w, 3), dtype=torch.uint8, device=dev)
+for s in a.sigmas:
+    rs = dataclasses.replace(baseline_config(3)[0], bloom_sigma=s)
+    pipe = FramePipeline(dev, a.h, a.w, rs, fps=30.0, noise_seed=1)
+    out = torch.empty_like(frames)
+    pipe.run(frames, out=out); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        pipe.run(frames, first_index=i * a.batch, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"sigma {s:5.2f}  radius {max(1, int(round(s * 3)) * 2 + 1) // 2:3d}  {a.batch * a.steps / dt:9.1f} frames/s  {dt / (a.batch * a.steps) * 1e6:8.1f} us/frame", flush=True)
