@@ -177,6 +177,13 @@ int crtfx_process_batch(crtfx_ctx* ctx, const void* frames_base, size_t frame_st
                         float* state_inout_dev, double persistence, int first_has_state,
                         float* local_states_base, void* stream);
 
+/* make_scanline_mask_2d (ref:308-328) computed on the device into out_dev (H x W float32, usable as
+ * crtfx_frame.scan_plane_dev): gain = 1 - strength * (0.5 * (1 + sin(omega * (y + tan_theta * x + phase_px)))) ^ inv_sharp
+ * in float64, cast to float32.  The caller passes omega = 2 pi / max(1e-6, period), tan_theta = tan(deg2rad(angle)),
+ * inv_sharp = 1 / clip(thickness, 0.1, 4) as the host computed them (ref:319-324). */
+int crtfx_scanline_plane(crtfx_ctx* ctx, double strength, double omega, double phase_px, double tan_theta, double inv_sharp,
+                         float* out_dev, void* stream);
+
 /* cv2.resize(state_prev, (W, H), INTER_LINEAR) of ref:689-690: the previous persistence state has another
  * size than this ctx's frames (the preview window was resized between ticks).  src_dev: src_h x src_w x 3
  * float32; dst_dev: H x W x 3 float32, then usable as state_inout_dev of crtfx_apply. */

@@ -225,7 +225,7 @@ GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax
 }
 
 size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
-    return ((size_t)rr_lds_fixed_floats(R, pix) + 16 * 3 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
+    return ((size_t)rr_lds_fixed_floats(R, pix) + 16 * 5 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -241,9 +241,10 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
     // build only for the full-chain gate set
     const int R = c->kp.R;
     const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
-    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.scan_plane &&
-           !kf.noise_plane && !kf.overlay_before && !((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) &&
-           ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after && (c->pix_fmt != CRTFX_PIX_F16 || folded);
+    // a per-pixel scanline plane and a coarse grain plane (grain_size > 1) are handled by the runtime-gate build only (uint8 frames)
+    const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1);
+    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane && !kf.overlay_before &&
+           ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after && (c->pix_fmt != CRTFX_PIX_F16 || (folded && !needs_runtime));
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
@@ -252,7 +253,11 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr CRTFX_RR_RADII(CRTFX_RR_ENTRY)};
 #undef CRTFX_RR_ENTRY
     const int R = c->kp.R;
-    const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    if (c->pix_fmt != CRTFX_PIX_F16) {
+        if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
+        for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane) folded = false;
+    }
     if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, g, g).seg;   // partial last group / single frames: planned once
     const int seg = c->seg_for[g];
     const int strips = (c->W + TW - 1) / TW;
@@ -536,7 +541,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         // 4K with 4 frames per grid = 398 MB and k_warp goes from 38 to 44 us per frame)
         int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
-        const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+        const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, 1, gcap);
         if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) { gp.g = v; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, v); } }
         if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) gp.seg = ((v + NB - 1) / NB) * NB; }
@@ -734,6 +739,16 @@ int crtfx_warp_map(crtfx_ctx* c, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_
     if (!c || !ix_dev || !iy_dev || !fxy_dev) return CRTFX_E_INVALID;
     if (!c->params_set || !(c->kp.flags & CRTFX_F_WARP)) return fail(c, CRTFX_E_INVALID, "warp is not enabled in the current params");
     hipLaunchKernelGGL(k_warp_map, dim3((c->W + 255) / 256, c->H), dim3(256), 0, (hipStream_t)stream, c->kp, ix_dev, iy_dev, fxy_dev);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_scanline_plane(crtfx_ctx* c, double strength, double omega, double phase_px, double tan_theta, double inv_sharp,
+                         float* out_dev, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (!out_dev) return fail(c, CRTFX_E_INVALID, "out_dev is NULL");
+    hipLaunchKernelGGL(k_scan_plane, dim3((c->W + 255) / 256, c->H), dim3(256), 0, (hipStream_t)stream, c->H, c->W, strength, omega,
+                       phase_px, tan_theta, inv_sharp, out_dev);
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
 }

@@ -245,6 +245,8 @@ struct PixMasks {
     float m0, m1, m2;   // triad mask RGB at this pixel
     float sl;           // scanline gain
     double vig;         // vignette gain (float64, ref:266-276)
+    float z;            // the pixel's N(0,1) grain sample when the caller has already formed it (has_z != 0)
+    int has_z;
 };
 
 __device__ __forceinline__ double vignette_gain(const KParams& P, double nx2, double ny2) {
@@ -329,7 +331,7 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
                 z = F.noise_plane ? F.noise_plane[idx] : grain_normal(F.key0, F.key1, idx);
             }
         } else {
-            z = grain_normal(F.key0, F.key1, idx);
+            z = M.has_z ? M.z : grain_normal(F.key0, F.key1, idx);
         }
         const float n = z * P.noise_scale;
         v0 = clip01(v0 + (T)n); v1 = clip01(v1 + (T)n); v2 = clip01(v2 + (T)n);
@@ -827,8 +829,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
     uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // uint8: [CR][TW] packed r|g<<8|b<<16.  half: [CR][3][TW] uint16 planes
     uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
-    uint32_t* rowtab = cring + (PIX ? (CR * TW * 3 + 1) / 2 : CR * TW);                              // [16][3] ring: scan gain bits, ny2 lo, ny2 hi of output row y at (y - y_begin) & 15
-    int* ytab = reinterpret_cast<int*>(rowtab + 16 * 3);                   // [seg_rows + 2R]: source row of halo row (pixelate)
+    uint32_t* rowtab = cring + (PIX ? (CR * TW * 3 + 1) / 2 : CR * TW);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
+    int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
     // prefetches).  Rotating the roles by the block's dispatch number spreads them over the SIMDs of a CU: measured
@@ -859,6 +861,16 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     float cm0 = 1.0f, cm1 = 1.0f, cm2 = 1.0f;
     if (fl & CRTFX_F_TRIAD) { cm0 = P.triad_row[xc * 3]; cm1 = P.triad_row[xc * 3 + 1]; cm2 = P.triad_row[xc * 3 + 2]; }
     const double cnx2 = row_vig ? P.vig_nx2[xc] : 0.0;
+    // Runtime-gate build only: a per-pixel scanline plane (slanted / shaped scanlines, ref:308-328) and the
+    // bilinear upsample of a coarse grain plane (grain_size > 1, ref:637-642).  The gate-folded builds keep
+    // neither (their launches never carry them: lean_ok / launch_rr_group).
+    constexpr bool RTB = (SF == 0xFFFFFFFFu);
+    const bool plane_scan = RTB && row_scan && F.scan_plane != nullptr;
+    const bool coarse_grain = RTB && (fl & CRTFX_F_NOISE) && P.grain > 1;
+    int cgxo = 0; float cgxa = 0.0f;
+    if (coarse_grain) { cgxo = P.gx_ofs[xc]; cgxa = P.gx_a[xc]; }
+    float pf_sp[2] = {1.0f, 1.0f}, sp_next[2] = {1.0f, 1.0f}, sp_c2[2] = {1.0f, 1.0f};   // plane gains of this thread's two C2 pixels: in flight, parked, in use
+    int pf_gyo = 0; float pf_gya = 0.0f;
 
     // the Gaussian taps are symmetric (taps[k] == taps[2R-k] bit for bit: tables.gaussian_taps mirrors them),
     // so only R+1 of them are ever read: 10 SGPRs instead of 19 live through both blur phases
@@ -898,8 +910,16 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         {
             const int yr = hb - R + tid;
             if (tid < NB && yr >= y_begin && yr < y_end) {
-                if (row_scan) pf_scan = F.scan_row[yr];
+                if (row_scan && !plane_scan) pf_scan = F.scan_row[yr];
                 if (row_vig) pf_ny2 = P.vig_ny2[yr];
+                if (coarse_grain) { pf_gyo = P.gy_ofs[yr]; pf_gya = P.gy_a[yr]; }
+            }
+        }
+        if (plane_scan) {                 // the two pixels this thread finishes in C2 of block hb: rows hb - R + wave (+ 4), column lane
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int yr = hb - R + wave + 4 * k;
+                if (yr >= y_begin && yr < y_end) pf_sp[k] = F.scan_plane[(size_t)yr * W + xc];
             }
         }
 #pragma unroll
@@ -926,15 +946,24 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             const int y = hbp - R + j;
             if (y >= y_begin && y < y_end) {                  // wave-uniform
                 float r = 0, g = 0, b = 0;
-                PixMasks M{cm0, cm1, cm2, 1.0f, 1.0};
+                PixMasks M{cm0, cm1, cm2, 1.0f, 1.0, 0.0f, 0};
                 if (xin) {
                     int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;
                     uint32_t s0, s1, s2;
                     if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
                     else { const uint32_t pk = cring[cr * TW + lane]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
-                    const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 3;
-                    M.sl = __uint_as_float(rt[0]);
+                    const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 5;
+                    M.sl = plane_scan ? (j >= 4 ? sp_c2[1] : sp_c2[0]) : __uint_as_float(rt[0]);
+                    if (coarse_grain) {        // ref:637-642: horizontal lerp of the two coarse rows, then the vertical one
+                        const int sx = cgxo, sy = (int)rt[3];
+                        const int sx1 = min(sx + 1, P.gw - 1), sy1 = min(sy + 1, P.gh - 1);
+                        const float a1 = cgxa, a0 = 1.0f - a1, b1 = __uint_as_float(rt[4]), b0 = 1.0f - b1;
+                        const float n00 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx), n01 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx1);
+                        const float n10 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx), n11 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx1);
+                        M.z = (n00 * a0 + n01 * a1) * b0 + (n10 * a0 + n11 * a1) * b1;
+                        M.has_z = 1;
+                    }
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
                     r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
                     grade(P, r, g, b);
@@ -978,8 +1007,13 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         {
             const int yr = hb - R + tid;                     // output row whose constants arrived with this block's bytes
             if (tid < NB && yr >= y_begin && yr < y_end) {
-                uint32_t* rt = rowtab + ((yr - y_begin) & 15) * 3;
+                uint32_t* rt = rowtab + ((yr - y_begin) & 15) * 5;
                 rt[0] = __float_as_uint(pf_scan); rt[1] = (uint32_t)__double2loint(pf_ny2); rt[2] = (uint32_t)__double2hiint(pf_ny2);
+                if (coarse_grain) { rt[3] = (uint32_t)pf_gyo; rt[4] = __float_as_uint(pf_gya); }
+            }
+            if (plane_scan) {      // C2 of the previous block runs later in this iteration with sp_c2; this block's values wait in sp_next
+                sp_c2[0] = sp_next[0]; sp_c2[1] = sp_next[1];
+                sp_next[0] = pf_sp[0]; sp_next[1] = pf_sp[1];
             }
         }
 #pragma unroll
@@ -1054,6 +1088,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             }
         }
         __syncthreads();
+        if (plane_scan) { sp_c2[0] = sp_next[0]; sp_c2[1] = sp_next[1]; }
         phase_c2(hb_last, htl);
     }
 #ifdef CRTFX_STAMP
@@ -1234,6 +1269,23 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
             }
         }
     }
+}
+#endif  // CRTFX_MAIN_TU
+
+#ifdef CRTFX_MAIN_TU
+// crtfx_scanline_plane — make_scanline_mask_2d (ref:308-328) on the device: the slanted / thickness-shaped scanline
+// gain the reference rebuilds on the CPU for every frame (float64 sin and pow per pixel, then cast to float32).
+// Same expression tree in double; the device's sin/pow are not numpy's, so a value can come out one float32 ulp
+// away from the host table when the double results straddle a float32 rounding boundary (rare: see
+// tests/test_parity_gpu.py::test_scanline_plane_on_device).
+__global__ void k_scan_plane(int H, int W, double strength, double omega, double phase, double tan_theta, double inv_sharp,
+                             float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const double slanted = (double)y + tan_theta * (double)x;
+    const double s = 0.5 * (1.0 + sin(omega * (slanted + phase)));
+    out[(size_t)y * W + x] = (float)(1.0 - strength * pow(s, inv_sharp));
 }
 #endif  // CRTFX_MAIN_TU
 

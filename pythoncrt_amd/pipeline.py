@@ -119,8 +119,15 @@ class FramePipeline:
                 for j in range(n):
                     recs[j].scan_row_dev = rows[j].data_ptr()
             else:
-                planes = torch.from_numpy(np.stack([tables.scanline_plane(self.h, self.w, st.scanline_strength, st.scanline_period_px,
-                                                                          ph, st.scanline_angle, st.scanline_thickness) for ph in phases])).to(self.device)
+                # slanted / shaped scanlines: the reference rebuilds an H x W float64 sin/pow mask per frame on the CPU
+                # (ref:308-328); here one small kernel per frame writes it on the device (crtfx_scanline_plane)
+                planes = torch.empty((n, self.h, self.w), dtype=torch.float32, device=self.device)
+                omega, tan_t, inv_sharp = tables.scanline_plane_scalars(st.scanline_period_px, st.scanline_angle, st.scanline_thickness)
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                with torch.cuda.device(self.device):
+                    for j, ph in enumerate(phases):
+                        _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_scanline_plane(
+                            self.engine.ctx, float(st.scanline_strength), omega, float(ph), tan_t, inv_sharp, planes[j].data_ptr(), stream))
                 hold.append(planes)
                 for j in range(n):
                     recs[j].scan_plane_dev = planes[j].data_ptr()

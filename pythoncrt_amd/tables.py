@@ -132,6 +132,15 @@ def scanline_plane(h: int, w: int, strength: float, period_px: float, phase_px: 
     return np.ascontiguousarray((1.0 - float(strength) * np.power(s, 1.0 / sharp)).astype(np.float32))
 
 
+def scanline_plane_scalars(period_px: float, angle_deg: float, thickness: float):
+    """(omega, tan(theta), 1/sharp) of make_scanline_mask_2d exactly as ref:319-324 computes them: the scalar
+    arguments of crtfx_scanline_plane."""
+    theta = np.deg2rad(float(angle_deg))
+    omega = 2.0 * np.pi / max(1e-6, float(period_px))
+    sharp = np.clip(float(thickness), 0.1, 4.0)
+    return float(omega), float(np.tan(theta)), float(1.0 / sharp)
+
+
 def flicker_factor(flicker_strength: float, flicker_hz: float, time_sec: float) -> float:
     """ref:632."""
     return float(1.0 + 0.25 * float(flicker_strength) * np.sin(2.0 * np.pi * float(flicker_hz) * float(time_sec)))

@@ -384,7 +384,9 @@ def test_kernel_variants_agree(pc, monkeypatch):
         dev = torch.device("cuda", torch.cuda.current_device())
         clip4 = torch.from_numpy(np.stack([make_frame(h, w, seed=61 + i, kind="grad") for i in range(4)])).to(dev)
         for rs in (RenderSettings(), RenderSettings(pixel_size=1, persistence=0.0), RenderSettings(warp_strength=0.2),
-                   baseline_config(2)[0], baseline_config(4)[0]):
+                   baseline_config(2)[0], baseline_config(4)[0],
+                   RenderSettings(fast_bloom=False, bloom_sigma=2.0, scanline_angle=12.0, scanline_thickness=2.0, grain_size=2, warp_strength=0.15),
+                   RenderSettings(fast_bloom=False, bloom_sigma=5.0, grain_size=3, pixel_size=1, persistence=0.0)):
             pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
             keep = torch.empty((4, h, w, 3), dtype=torch.float32, device=dev) if rs.persistence > 0 else None
             o, st = pipe.run(clip4, first_index=2, local_states=keep)
@@ -732,3 +734,27 @@ def test_two_worker_threads_like_process_video(pc):
     for i in range(n):
         assert got[i].dtype == np.float32 and np.array_equal(got[i], single[i]), i
     assert np.array_equal(commit(got), commit(single))
+
+
+def test_scanline_plane_on_device(pc):
+    """make_scanline_mask_2d (ref:308-328) generated by crtfx_scanline_plane against the host table built with the
+    reference's numpy expression: float64 sin/pow of the device are not numpy's, so single values may land one
+    float32 ulp away; the bar is <= 1 ulp anywhere and <= 1e-5 of the elements off at all."""
+    from pythoncrt_amd import tables
+    from pythoncrt_amd.effects import _engine
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for (h, w, strength, period, phase, angle, thick) in [(270, 480, 0.6, 2.0, 3.25, 12.0, 1.0), (135, 333, 1.0, 3.7, -17.5, -40.0, 2.5),
+                                                          (64, 64, 0.35, 1.0, 250.0, 0.0, 0.3), (1080, 1920, 0.6, 2.0, 41.0, 7.0, 4.0)]:
+        eng = _engine(dev, h, w)
+        out = torch.empty((h, w), dtype=torch.float32, device=dev)
+        omega, tan_t, inv_sharp = tables.scanline_plane_scalars(period, angle, thick)
+        rc = eng.lib.crtfx_scanline_plane(eng.ctx, strength, omega, phase, tan_t, inv_sharp, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        got = out.cpu().numpy()
+        exp = tables.scanline_plane(h, w, strength, period, phase, angle, thick)
+        assert np.array_equal(exp, orc.make_scanline_mask_2d(h, w, strength, period, phase, angle, thick))
+        off = got != exp
+        assert off.mean() <= 1e-5, off.mean()
+        if off.any():
+            ulp = np.spacing(np.maximum(np.abs(exp[off]), np.float32(2.0 ** -20)))
+            assert (np.abs(got[off].astype(np.float64) - exp[off]) <= ulp).all()
