@@ -253,9 +253,14 @@ class Engine:
                 t = torch.from_numpy(row).to(self.device, non_blocking=False)
                 f.scan_row_dev = t.data_ptr()
             else:
-                plane = tables.scanline_plane(h, w, s.scanline_strength, s.scanline_period_px, scanline_phase_px,
-                                              s.scanline_angle, s.scanline_thickness)
-                t = torch.from_numpy(plane).to(self.device)
+                # make_scanline_mask_2d (ref:308-328) on the device: the host version is an H x W float64 sin/pow per
+                # call (40 ms at 1080p, a stall per GUI tick); within one float32 ulp of it (crtfx_scanline_plane)
+                t = torch.empty((h, w), dtype=torch.float32, device=self.device)
+                omega, tan_t, inv_sharp = tables.scanline_plane_scalars(s.scanline_period_px, s.scanline_angle, s.scanline_thickness)
+                with torch.cuda.device(self.device):
+                    _lib.check(self.lib, self.ctx, self.lib.crtfx_scanline_plane(
+                        self.ctx, float(s.scanline_strength), omega, float(scanline_phase_px), tan_t, inv_sharp, t.data_ptr(),
+                        _stream_ptr(self.device)))
                 f.scan_plane_dev = t.data_ptr()
             hold.append(t)
         f.flicker_factor = tables.flicker_factor(s.flicker_strength, s.flicker_hz, time_sec) if (self.flags & _lib.F_FLICKER) else 1.0
