@@ -120,8 +120,10 @@ typedef struct crtfx_frame {
     uint64_t frame_index;            /* RNG counter high part */
     int32_t  overlay_after;          /* ref:588 vs :653 */
     int32_t  glitch_y0;              /* first row of the glitch band  ref:667 */
-    int32_t  glitch_cols;            /* 1 (per-row, preview ref:682) or W (per-pixel, render ref:855) */
-    int32_t  reserved0;
+    int32_t  glitch_cols;            /* offsets per band row: 1 (per-row, preview ref:682), W (per-pixel, render ref:855), or the
+                                      * number of segments when glitch_seg_len > 0 */
+    int32_t  glitch_seg_len;         /* > 0: pixel x takes offsets[row * glitch_cols + x / glitch_seg_len] (the render variant's
+                                      * per-segment offsets, ref:843-852, before their expansion to pixels); 0: see glitch_cols */
 } crtfx_frame;
 
 /* Persistence blend flavours. */

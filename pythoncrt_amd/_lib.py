@@ -55,7 +55,7 @@ class CrtfxFrame(ctypes.Structure):
         ("overlay_rgba_dev", _vp), ("glitch_offs_dev", _vp),
         ("flicker_factor", ctypes.c_double), ("noise_seed", ctypes.c_uint64), ("frame_index", ctypes.c_uint64),
         ("overlay_after", ctypes.c_int32), ("glitch_y0", ctypes.c_int32), ("glitch_cols", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("glitch_seg_len", ctypes.c_int32),
     ]
 
 

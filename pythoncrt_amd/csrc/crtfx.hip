@@ -340,7 +340,10 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);
     const bool ov_after = f && f->overlay_rgba_dev && f->overlay_after;
     const bool glitch = f && f->glitch_offs_dev;
-    if (glitch && !(f->glitch_cols == 1 || f->glitch_cols == c->W))
+    if (glitch && f->glitch_seg_len < 0) return fail(c, CRTFX_E_INVALID, "glitch_seg_len is negative");
+    if (glitch && f->glitch_seg_len > 0 && f->glitch_cols != (c->W + f->glitch_seg_len - 1) / f->glitch_seg_len)
+        return fail(c, CRTFX_E_INVALID, "glitch_cols must be ceil(W / glitch_seg_len)");
+    if (glitch && f->glitch_seg_len == 0 && !(f->glitch_cols == 1 || f->glitch_cols == c->W))
         return fail(c, CRTFX_E_INVALID, "glitch_cols must be 1 or W");
     if (glitch && (f->glitch_y0 < 0 || f->glitch_y0 >= c->H)) return fail(c, CRTFX_E_INVALID, "glitch_y0 outside the frame");
     // Two-kernel path (pre-warp float32 image + k_warp): warp on; a glitch gather; or a persistence blend
@@ -349,7 +352,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     // exactly as ref:653-662 does.
     const bool two = warp || glitch || (gauss && ko.blend != CRTFX_BLEND_NONE);
     if (ov_after) ko.overlay_after = f->overlay_rgba_dev;
-    if (glitch) { ko.glitch_offs = f->glitch_offs_dev; ko.glitch_y0 = f->glitch_y0; ko.glitch_cols = f->glitch_cols; }
+    if (glitch) { ko.glitch_offs = f->glitch_offs_dev; ko.glitch_y0 = f->glitch_y0; ko.glitch_cols = f->glitch_cols; ko.glitch_seg_len = f->glitch_seg_len; }
     KOut k1 = ko;
     if (two) { k1 = KOut{}; k1.pre = c->pre; }
     k1.dbg = c->dbg;

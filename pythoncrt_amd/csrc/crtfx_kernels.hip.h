@@ -85,7 +85,7 @@ struct KOut {
     double p, q;         // persistence, 1 - persistence (double, as python computes them)
     const uint8_t* __restrict__ overlay_after;   // H x W x 4 RGBA blended after the warp (ref:653-663), or nullptr
     const int* __restrict__ glitch_offs;         // x offsets of the glitch band (ref:679-682 / 853-855), or nullptr
-    int glitch_y0, glitch_cols;                  // first band row; 1 offset per row or W per row
+    int glitch_y0, glitch_cols, glitch_seg_len;  // first band row; offsets per row (1, W, or segments of glitch_seg_len pixels)
     unsigned long long* dbg;   // CRTFX_STAMP diagnostic build only: per-wave phase cycle sums
 };
 
@@ -1167,7 +1167,8 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int ident
         // band, post being the warped + overlaid image — so everything upstream is evaluated at column xs.
         int xs = x;
         if (O.glitch_offs && y >= O.glitch_y0) {
-            const int off = O.glitch_offs[(size_t)(y - O.glitch_y0) * O.glitch_cols + (O.glitch_cols == 1 ? 0 : x)];
+            const int col = O.glitch_seg_len > 0 ? x / O.glitch_seg_len : (O.glitch_cols == 1 ? 0 : x);
+            const int off = O.glitch_offs[(size_t)(y - O.glitch_y0) * O.glitch_cols + col];
             xs = (x + off) % P.W;
             if (xs < 0) xs += P.W;
         }

@@ -243,10 +243,11 @@ class Engine:
             f.overlay_rgba_dev = ov.data_ptr()
             f.overlay_after = 1 if overlay_after else 0
         if glitch is not None and glitch[1] is not None:
-            y0, offs = glitch
+            y0, offs = glitch[0], glitch[1]
             t = torch.from_numpy(offs).to(self.device)
             hold.append(t)
             f.glitch_offs_dev, f.glitch_y0, f.glitch_cols = t.data_ptr(), int(y0), int(offs.shape[1])
+            f.glitch_seg_len = int(glitch[2]) if len(glitch) > 2 else 0
         if s.scanline_strength > 0.0:
             if s.scanline_angle == 0.0 and s.scanline_thickness == 1.0:       # ref:619
                 row = tables.scanline_rows(h, s.scanline_strength, s.scanline_period_px, [scanline_phase_px])[0]
@@ -489,7 +490,7 @@ def apply_static_effects(
     hold = []
     glitch = None
     if glitch_amp_px > 0 and glitch_height_frac > 0.0:                      # ref:835 — render variant
-        glitch = tables.glitch_offsets_render(h, w, scanline_phase_px, glitch_amp_px, glitch_height_frac)
+        glitch = tables.glitch_offsets_render_segments(h, w, scanline_phase_px, glitch_amp_px, glitch_height_frac)
     rec = eng.frame_record(s, scanline_phase_px, time_sec, noise_seed, frame_index, noise_plane, hold,
                            overlay=text_overlay_rgba, overlay_after=text_overlay_after, glitch=glitch)
     img = torch.empty((h, w, 3), dtype=torch.float32, device=fr.device)

@@ -135,11 +135,12 @@ class FramePipeline:
         if rs.glitch_amp_px > 0 and rs.glitch_height_frac > 0.0:                                    # ref:835-859, render variant
             for j, i in enumerate(idx):
                 ph = (int(i) / float(self.fps)) * rs.scanline_speed_px_s
-                y0, offs = tables.glitch_offsets_render(self.h, self.w, ph, rs.glitch_amp_px, rs.glitch_height_frac)
+                y0, offs, seg_len = tables.glitch_offsets_render_segments(self.h, self.w, ph, rs.glitch_amp_px, rs.glitch_height_frac)
                 if offs is not None:
                     t = torch.from_numpy(offs).to(self.device)
                     hold.append(t)
                     recs[j].glitch_offs_dev, recs[j].glitch_y0, recs[j].glitch_cols = t.data_ptr(), int(y0), int(offs.shape[1])
+                    recs[j].glitch_seg_len = int(seg_len)
         for j, i in enumerate(idx):
             recs[j].flicker_factor = tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) if flick else 1.0  # ref:1064
             recs[j].noise_seed = self.noise_seed & 0xFFFFFFFFFFFFFFFF
