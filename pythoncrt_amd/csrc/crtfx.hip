@@ -153,7 +153,7 @@ struct ProfEv {
     }
 };
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bool runtime = false);
 
 // Rows per k_phosphor block.  Every block of the grid should be resident at once (a second,
 // partial round of blocks costs a whole extra block lifetime), so the grid is sized to the
@@ -187,7 +187,7 @@ struct GridPlan { int g, seg; };
 GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax_allowed) {
     const int strips = (W + TW - 1) / TW;
     const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
-    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix);
+    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded && pix != CRTFX_PIX_F16);
     int bpc = (int)(163840 / lds);
     const int by_regs = rr_min_waves(Rk, folded || pix == CRTFX_PIX_F16);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
@@ -224,8 +224,8 @@ GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax
     return best;
 }
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix) {
-    return ((size_t)rr_lds_fixed_floats(R, pix) + 16 * 5 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix, bool runtime) {
+    return ((size_t)rr_lds_fixed_floats(R, pix, runtime) + 16 * 5 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -264,7 +264,7 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     const int segs = (c->H + seg - 1) / seg;
     const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
     ProfEv pe(c, 0, g);
-    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt),
+    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, variant == 0),
              s, variant, pe.e0, pe.e1);
 }
 

@@ -782,7 +782,15 @@ __host__ __device__ constexpr int rr_swp(int R) { return TW + 2 * rr_pad(R); }
 __host__ __device__ constexpr int rr_sws(int R, int pix = 0) { return pix ? (rr_swp(R) + 31) & ~31 : (rr_swp(R) + 63) & ~63; }
 __host__ __device__ constexpr int rr_cring(int R) { return R + 2 * NB; }   // exact: LDS is what caps blocks per CU
 // LDS floats: staging, two H/blur row tiles, LUTs, centre ring (u32); then per-row table + pixelate rows
-__host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix) { return NB * 3 * rr_sws(R, pix) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + (pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW); }
+// The runtime-gate build (uint8 frames) parks the GRADED float pixel (3 floats) instead of the packed bytes: it is
+// register-limited to 3 resident blocks per CU anyway, so the extra LDS is free and C2 does not redo a1 + a4 (with
+// --gamma that is three powf per pixel).
+__host__ __device__ constexpr int rr_cring_floats(int R, int pix, bool runtime) {
+    return runtime ? rr_cring(R) * TW * 3 : (pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW);
+}
+__host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix, bool runtime = false) {
+    return NB * 3 * rr_sws(R, pix || runtime) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring_floats(R, pix, runtime);
+}
 
 // SF: the stage gates (crtfx_params.flags without CRTFX_F_WARP, which k_phosphor never reads) as a
 // compile-time constant, or SF_RUNTIME.  With the gates folded the dead stages, their parameters
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     constexpr int R = RT, K = 2 * R + 1;
     constexpr int pad = rr_pad(R);
     constexpr int SWP = rr_swp(R);
-    constexpr int SWS = rr_sws(R, PIX);
+    constexpr int SWS = rr_sws(R, PIX || SF == 0xFFFFFFFFu);     // 32-dword multiple for the builds whose LDS budget is tight
     constexpr int L = 2 * R + NB;               // register window length
     constexpr int CR = rr_cring(R);             // centre ring rows: R + 2 NB
     constexpr int A_ITEMS = (NB * SWP + RR_THREADS - 1) / RR_THREADS;
@@ -829,7 +837,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     float* lut = hrow + 2 * HT;                 // [2][LUT_STRIDE]
     uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);   // uint8: [CR][TW] packed r|g<<8|b<<16.  half: [CR][3][TW] uint16 planes
     uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
-    uint32_t* rowtab = cring + (PIX ? (CR * TW * 3 + 1) / 2 : CR * TW);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
+    float* cringf = reinterpret_cast<float*>(cring);                        // runtime-gate build: [CR][3][TW] graded floats
+    uint32_t* rowtab = cring + rr_cring_floats(R, PIX, SF == 0xFFFFFFFFu);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
     int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
@@ -950,8 +959,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
                 if (xin) {
                     int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;
-                    uint32_t s0, s1, s2;
-                    if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
+                    uint32_t s0 = 0, s1 = 0, s2 = 0;
+                    if constexpr (RTB) { const float* cp = cringf + cr * 3 * TW + lane; r = cp[0]; g = cp[TW]; b = cp[2 * TW]; }
+                    else if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
                     else { const uint32_t pk = cring[cr * TW + lane]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
                     const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 5;
                     M.sl = plane_scan ? (j >= 4 ? sp_c2[1] : sp_c2[0]) : __uint_as_float(rt[0]);
@@ -965,8 +975,10 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
                         M.has_z = 1;
                     }
                     if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
-                    r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
-                    grade(P, r, g, b);
+                    if constexpr (!RTB) {
+                        r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
+                        grade(P, r, g, b);
+                    }
                     r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
                     g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
                     b = clip01(b + P.bloom_strength * ht[(j * 3 + 2) * TW + lane]);
@@ -1021,14 +1033,15 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             const int it = tid + u * RR_THREADS;
             const int j = it / SWP, i = it - j * SWP;
             if (j < nrows) {
-                if (i >= pad && i < pad + TW) {     // centre column: park the packed samples for C2
-                    int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division
-                    cr = cr >= CR ? cr - CR : cr;
-                    if constexpr (PIX) { uint16_t* cp = cring16 + cr * 3 * TW + (i - pad); cp[0] = (uint16_t)raw[u].r; cp[TW] = (uint16_t)raw[u].g; cp[2 * TW] = (uint16_t)raw[u].b; }
-                    else cring[cr * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
-                }
                 float r = norm_px(PIX, raw[u].r), g = norm_px(PIX, raw[u].g), b = norm_px(PIX, raw[u].b);
                 grade(P, r, g, b);
+                if (i >= pad && i < pad + TW) {     // centre column: park the pixel for C2 (graded floats, or the packed samples)
+                    int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division
+                    cr = cr >= CR ? cr - CR : cr;
+                    if constexpr (RTB) { float* cp = cringf + cr * 3 * TW + (i - pad); cp[0] = r; cp[TW] = g; cp[2 * TW] = b; }
+                    else if constexpr (PIX) { uint16_t* cp = cring16 + cr * 3 * TW + (i - pad); cp[0] = (uint16_t)raw[u].r; cp[TW] = (uint16_t)raw[u].g; cp[2 * TW] = (uint16_t)raw[u].b; }
+                    else cring[cr * TW + (i - pad)] = raw[u].r | (raw[u].g << 8) | (raw[u].b << 16);
+                }
                 float* s = stg + (j * 3) * SWS + i;
                 s[0] = bloom_src(P, r); s[SWS] = bloom_src(P, g); s[2 * SWS] = bloom_src(P, b);
             }

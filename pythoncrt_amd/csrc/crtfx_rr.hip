@@ -17,8 +17,17 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else if (variant == 1)
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
-    else
+    else {
+        if (lds > 65536) {      // large radii park up to 35 KB of graded centre pixels: above the default dynamic-LDS limit
+            static bool raised = false;
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised = true;
+            }
+        }
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    }
 }
 
 }  // namespace crtfx
