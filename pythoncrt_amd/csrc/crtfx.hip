@@ -242,9 +242,10 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
     const int R = c->kp.R;
     const bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
     // a per-pixel scanline plane and a coarse grain plane (grain_size > 1) are handled by the runtime-gate build only (uint8 frames)
-    const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1);
-    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane && !kf.overlay_before &&
-           ko.blend == CRTFX_BLEND_NONE && !ko.overlay_after && (c->pix_fmt != CRTFX_PIX_F16 || (folded && !needs_runtime));
+    // (text overlays before the effects, or after them when the same kernel also commits) are handled by the runtime-gate build only
+    const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) || kf.overlay_before || ko.overlay_after;
+    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
+           ko.blend == CRTFX_BLEND_NONE && (c->pix_fmt != CRTFX_PIX_F16 || (folded && !needs_runtime));
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
@@ -256,7 +257,7 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
     if (c->pix_fmt != CRTFX_PIX_F16) {
         if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
-        for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane) folded = false;
+        for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     }
     if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, g, g).seg;   // partial last group / single frames: planned once
     const int seg = c->seg_for[g];
@@ -650,6 +651,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         ko.pix = c->pix_fmt;
         ko.out_u8 = out_base ? static_cast<uint8_t*>(out_base) + (size_t)i * out_stride_bytes : nullptr;
         ko.p = persistence; ko.q = 1.0 - persistence;
+        if (frames && frames[i].overlay_rgba_dev && frames[i].overlay_after) ko.overlay_after = frames[i].overlay_rgba_dev;
         if (blend_on) {
             ko.state = state_inout_dev; ko.blend = (i > 0 || first_has_state) ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE;
             if (local_states_base) {     // per-frame states wanted: frame i reads state i-1 and writes state i in place of a copy per frame
@@ -674,7 +676,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 const crtfx_frame* f = frames ? &frames[i + g] : nullptr;
                 if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev)))
                     return fail(c, CRTFX_E_INVALID, "scanlines are on but the frame record carries no scan_row_dev / scan_plane_dev");
-                if (f && (f->overlay_rgba_dev || f->glitch_offs_dev)) break;
+                if (f && f->glitch_offs_dev) break;
                 KFrame kf = make_kframe(frame_in(i + g), f);
                 KOut k1{};
                 if (two) { k1.pre = c->pre + ((size_t)slot * c->group_max + g) * frame_elems; k1.pix = c->pix_fmt; } else k1 = final_out(i + g);

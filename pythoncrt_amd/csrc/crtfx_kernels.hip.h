@@ -201,8 +201,13 @@ __device__ __forceinline__ void grade(const KParams& P, float& r, float& g, floa
 // text overlay (ref:588-598 / 653-663): alpha = a/255, rgb = c/255 (float32); img*(1-alpha) + rgb*alpha in the
 // image dtype, the rgb*alpha product in float32 (both factors are float32 arrays), then clip.
 template <typename T>
+__device__ __forceinline__ void overlay_blend_px(uint32_t px, T& v0, T& v1, T& v2);
+template <typename T>
 __device__ __forceinline__ void overlay_blend(const uint8_t* __restrict__ ov, uint32_t pix, T& v0, T& v1, T& v2) {
-    const uint32_t px = *reinterpret_cast<const uint32_t*>(ov + (size_t)pix * 4);
+    overlay_blend_px<T>(*reinterpret_cast<const uint32_t*>(ov + (size_t)pix * 4), v0, v1, v2);
+}
+template <typename T>
+__device__ __forceinline__ void overlay_blend_px(uint32_t px, T& v0, T& v1, T& v2) {
     const float a = norm_u8(px >> 24), ia = 1.0f - a;
     const float c0 = norm_u8(px & 255u) * a, c1 = norm_u8((px >> 8) & 255u) * a, c2 = norm_u8((px >> 16) & 255u) * a;
     v0 = clip01(v0 * (T)ia + (T)c0); v1 = clip01(v1 * (T)ia + (T)c1); v2 = clip01(v2 * (T)ia + (T)c2);
@@ -439,7 +444,9 @@ __device__ __forceinline__ PackedPix commit_pixel(const KOut& O, uint32_t pix, T
 
 // One finished pre-warp pixel: either park it for k_warp or commit it.
 // Every lane of the wavefront must call this (store_row_u8 shuffles); `live` masks the pixel.
-template <bool LEAN = false>
+// LEAN: no per-pixel planes in the tail; COMMIT: overlay-after / blend compiled into the commit (the host routes such
+// launches elsewhere when it is off).
+template <bool LEAN = false, bool COMMIT = !LEAN>
 __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, const KOut& O, int y, int x0, int lane,
                                            bool live, const PixMasks& M, float r, float g, float b,
                                            const float* lut_g, const float* lut_inv) {
@@ -453,7 +460,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
             if (live) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
             return;
         }
-        if (live) packed = commit_pixel<double, !LEAN>(O, pix, v0, v1, v2);
+        if (live) packed = commit_pixel<double, COMMIT>(O, pix, v0, v1, v2);
     } else {
         float v0 = 0, v1 = 0, v2 = 0;
         if (live) tail_masks<float, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
@@ -461,7 +468,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
             if (live) { float* p = O.pre + pix * 3u; p[0] = v0; p[1] = v1; p[2] = v2; }
             return;
         }
-        if (live) packed = commit_pixel<float, !LEAN>(O, pix, v0, v1, v2);
+        if (live) packed = commit_pixel<float, COMMIT>(O, pix, v0, v1, v2);
     }
     if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), packed);
 }
@@ -909,6 +916,17 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         if (P.ab != 0) { xr = wrap(x - P.ab, W); xb = wrap(x + P.ab, W); }      // ref:573-575
         offr[u] = (uint32_t)xr * 3u; offg[u] = (uint32_t)x * 3u + 1u; offb[u] = (uint32_t)xb * 3u + 2u;
     }
+    // runtime-gate build: text overlay blended after the grade (ref:588-598), i.e. before the bloom sees the image.
+    // The overlay pixel of a staged halo position is the one at its clamped (BORDER_REPLICATE) frame position — the
+    // pixelate maps do not apply to it (a3 comes before the overlay).
+    const bool ovl_before = RTB && F.overlay_before != nullptr;
+    uint32_t ovx[A_ITEMS], ovpx[A_ITEMS];
+#pragma unroll
+    for (int u = 0; u < A_ITEMS; ++u) {
+        const int it = tid + u * RR_THREADS;
+        ovx[u] = (uint32_t)min(max(x0 - pad + (it - (it / SWP) * SWP), 0), W - 1);
+        ovpx[u] = 0u;
+    }
     __syncthreads();                                // ytab / rowtab / lut visible
     RawRGB raw[A_ITEMS];
     float pf_scan = 1.0f;                                  // per-row constants of output row hb - R + tid (threads < NB),
@@ -939,6 +957,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
                 const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
                 const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_bytes);   // y, row_bytes < 2^24 and the product < 2^32 for any frame the ctx accepts (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate)
                 raw[u] = load_raw(PIX, F.in, ro + offr[u], ro + offg[u], ro + offb[u]);
+                if (ovl_before)
+                    ovpx[u] = reinterpret_cast<const uint32_t*>(F.overlay_before)[(uint32_t)min(max(hb + j, 0), H - 1) * (uint32_t)W + ovx[u]];
             }
         }
     };
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
                     g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
                     b = clip01(b + P.bloom_strength * ht[(j * 3 + 2) * TW + lane]);
                 }
-                emit_pixel<true>(P, F, O, y, x0, lane, xin, M, r, g, b, lut, lut + LUT_STRIDE);
+                emit_pixel<true, RTB>(P, F, O, y, x0, lane, xin, M, r, g, b, lut, lut + LUT_STRIDE);
             }
         }
     };
@@ -1035,6 +1055,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             if (j < nrows) {
                 float r = norm_px(PIX, raw[u].r), g = norm_px(PIX, raw[u].g), b = norm_px(PIX, raw[u].b);
                 grade(P, r, g, b);
+                if (ovl_before) overlay_blend_px<float>(ovpx[u], r, g, b);
                 if (i >= pad && i < pad + TW) {     // centre column: park the pixel for C2 (graded floats, or the packed samples)
                     int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--sigmas", type=float, nargs="+", default=[1.2, 3.0, 4.0, 4.5, 6.5, 10.0])
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--overlay", choices=["none", "before", "after"], default="none", help="a text overlay blended before / after the effects")
 ap.add_argument("--set", nargs="*", default=[], metavar="field=value", help="RenderSettings overrides, e.g. scanline_angle=12 grain_size=2")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -21,7 +22,11 @@ for s in a.sigmas:
         cur = getattr(baseline_config(3)[0], k)
         over[k] = type(cur)(v) if not isinstance(cur, bool) else v.lower() in ("1", "true")
     rs = dataclasses.replace(baseline_config(3)[0], bloom_sigma=s, **over)
-    pipe = FramePipeline(dev, a.h, a.w, rs, fps=30.0, noise_seed=1)
+    ov = None
+    if a.overlay != "none":
+        from pythoncrt_amd.text import make_text_overlay_rgba
+        ov = make_text_overlay_rgba(a.w, a.h, "PythonCRT on MI355X", "", 96, "#FFCC00", (64, 64))
+    pipe = FramePipeline(dev, a.h, a.w, rs, fps=30.0, noise_seed=1, text_overlay_rgba=ov, text_overlay_after=(a.overlay == "after"))
     out = torch.empty_like(frames)
     pipe.run(frames, out=out); torch.cuda.synchronize()
     t0 = time.perf_counter()
