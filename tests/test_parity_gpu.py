@@ -758,3 +758,55 @@ def test_scanline_plane_on_device(pc):
         if off.any():
             ulp = np.spacing(np.maximum(np.abs(exp[off]), np.float32(2.0 ** -20)))
             assert (np.abs(got[off].astype(np.float64) - exp[off]) <= ulp).all()
+
+
+# ---- BASELINE full sizes through the render loop ----------------------------------------------------------------
+
+def _export_planes(pipe, seed, first, n, h, w):
+    out = []
+    for i in range(n):
+        p = torch.empty((h, w), dtype=torch.float32, device=pipe.device)
+        assert pipe.lib.crtfx_noise_plane(pipe.engine.ctx, seed, first + i, p.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        out.append(p.cpu().numpy())
+    return out
+
+
+def test_4k_render_loop_against_oracle(pc):
+    """BASELINE configs[2] (the bench workload: 4K, bloom sigma 3, warp 0.15) through crtfx_process_batch — the grouped
+    launch, the gate-folded k_phosphor_rr<9>, k_warp_lean, the in-kernel grain — against the oracle's in-order render
+    of the same two frames (about ten seconds of CPU)."""
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs, h, w = baseline_config(3)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, first, seed = 2, 7, 4242
+    frames = np.stack([make_frame(h, w, seed=300 + i, kind="grad") for i in range(n)])
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed)
+    out, _ = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    planes = _export_planes(pipe, seed, first, n, h, w)
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma",
+                                          "bloom_strength", "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom",
+                                          "pixel_size", "warp_strength")}
+    exp, _ = orc.process_frames(list(frames), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength, noise_planes=planes, first_index=first)
+    d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3, (int(d.max()), float((d != 0).mean()))
+
+
+def test_8k_fp16_batch_properties(pc):
+    """BASELINE configs[4]: 8K frames held as float16 in and out.  A batch equals its frames run one by one, is
+    deterministic, finite, and its top-left 64 x 64 block (where the warp samples outside the frame) is zero."""
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs, h, w = baseline_config(5)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(8)
+    frames = (torch.rand((2, h, w, 3), generator=g) * 255.0).to(torch.float16).to(dev)
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=77, dtype=torch.float16)
+    both, _ = pipe.run(frames, first_index=3)
+    again, _ = pipe.run(frames, first_index=3)
+    assert both.dtype == torch.float16 and torch.equal(both, again)
+    for i in range(2):
+        one, _ = pipe.run(frames[i:i + 1], first_index=3 + i)
+        assert torch.equal(one[0], both[i])
+    assert bool(torch.isfinite(both.float()).all()) and float(both.min()) >= 0.0 and float(both.max()) <= 255.0
+    assert not bool(both[:, :64, :64].any())
+    assert float(both[:, h // 2 - 200:h // 2 + 200, w // 2 - 200:w // 2 + 200].float().mean()) > 20.0
