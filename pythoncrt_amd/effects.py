@@ -89,6 +89,7 @@ def make_vignette(h: int, w: int, strength: float) -> VignetteMask:
 # ---------------------------------------------------------------------------------------
 
 _tls = threading.local()
+_ENGINES_PER_THREAD = 6     # contexts kept per thread (one per frame size / pixel format in use)
 _seed_lock = threading.Lock()
 _seed_counter = [int.from_bytes(os.urandom(8), "little")]
 
@@ -315,9 +316,12 @@ def _engine(device: torch.device, h: int, w: int, pix_fmt: int = _lib.PIX_U8) ->
     if cache is None:
         cache = _tls.engines = {}
     k = (device.index, h, w, pix_fmt)
-    e = cache.get(k)
+    e = cache.pop(k, None)
     if e is None:
-        e = cache[k] = Engine(device, h, w, pix_fmt)
+        e = Engine(device, h, w, pix_fmt)
+    cache[k] = e                      # most recently used last
+    while len(cache) > _ENGINES_PER_THREAD:      # a preview window dragged through many sizes must not pin a ctx
+        cache.pop(next(iter(cache)))             # (scratch images, tables) per size for ever: Engine.__del__ frees it
     return e
 
 

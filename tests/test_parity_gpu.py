@@ -810,3 +810,16 @@ def test_8k_fp16_batch_properties(pc):
     assert bool(torch.isfinite(both.float()).all()) and float(both.min()) >= 0.0 and float(both.max()) <= 255.0
     assert not bool(both[:, :64, :64].any())
     assert float(both[:, h // 2 - 200:h // 2 + 200, w // 2 - 200:w // 2 + 200].float().mean()) > 20.0
+
+
+def test_engine_cache_is_bounded(pc):
+    """A preview window dragged through many sizes: the per-thread ctx cache keeps the most recent few and frees the rest."""
+    from pythoncrt_amd import effects
+    a = lambda f: (f, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0)
+    first = make_frame(20, 30, seed=1)
+    ref = pc.apply_static_effects(*a(first))
+    for k in range(10):
+        pc.apply_static_effects(*a(make_frame(21 + k, 40 + 3 * k, seed=2 + k)))
+    assert len(effects._tls.engines) <= effects._ENGINES_PER_THREAD
+    assert (torch.cuda.current_device(), 20, 30, 0) not in effects._tls.engines       # evicted ...
+    assert np.array_equal(pc.apply_static_effects(*a(first)), ref)                    # ... and rebuilt on demand
