@@ -106,6 +106,11 @@ typedef struct crtfx_params {
     const int32_t* fbu_yofs; const float* fbu_yw;       /* H */
     const int32_t* fbd_xofs; const float* fbd_xw;       /* max(1,W//2): frame -> half-res          ref:606; NULL = exact 2x */
     const int32_t* fbd_yofs; const float* fbd_yw;       /* max(1,H//2)    decimation (OpenCV's INTER_AREA 2x2 mean) */
+    /* Optional (uint8 frames, saturation == 1): a1 + a4 tabulated per channel and code, 3 x 256 float32 = the value
+     * ref:569 + ref:292-304 give channel c of a pixel whose stored sample is u (temperature gain, brightness /
+     * contrast, gamma are all per-channel functions of the sample once the saturation mix is off).  Built on the
+     * host with the reference's numpy expressions; replaces the per-pixel arithmetic (three powf with --gamma). */
+    const float*  grade_lut;
 } crtfx_params;
 
 /* Per-frame inputs (everything that changes from frame to frame; ref:1043,1064). */

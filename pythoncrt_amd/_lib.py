@@ -46,6 +46,7 @@ class CrtfxParams(ctypes.Structure):
         ("grain_w", ctypes.c_int32), ("grain_h", ctypes.c_int32),
         ("fbu_xofs", _vp), ("fbu_xw", _vp), ("fbu_yofs", _vp), ("fbu_yw", _vp),
         ("fbd_xofs", _vp), ("fbd_xw", _vp), ("fbd_yofs", _vp), ("fbd_yw", _vp),
+        ("grade_lut", _vp),
     ]
 
 

@@ -31,7 +31,7 @@ struct crtfx_ctx {
     int pix_fmt = CRTFX_PIX_U8;
     bool params_set = false;
     KParams kp{};
-    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap;
+    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
@@ -153,7 +153,7 @@ struct ProfEv {
     }
 };
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bool runtime = false);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bool runtime = false, bool glut = false);
 
 // Rows per k_phosphor block.  Every block of the grid should be resident at once (a second,
 // partial round of blocks costs a whole extra block lifetime), so the grid is sized to the
@@ -184,10 +184,10 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
 // measured landscape (4K, R = 9: g=1/seg=128 -> 19 it/frame = 89 us; g=2/seg=256 -> 17.5 = 82.5 us, the short
 // last-segment blocks freeing slots for the overflow; g=2/seg=240 -> two full rounds = 103 us).
 struct GridPlan { int g, seg; };
-GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax_allowed) {
+GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed) {
     const int strips = (W + TW - 1) / TW;
     const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
-    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded && pix != CRTFX_PIX_F16);
+    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded && pix != CRTFX_PIX_F16, glut);
     int bpc = (int)(163840 / lds);
     const int by_regs = rr_min_waves(Rk, folded || pix == CRTFX_PIX_F16);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
@@ -224,8 +224,8 @@ GridPlan plan_grid(int H, int W, int R, int pix, bool folded, int gmin, int gmax
     return best;
 }
 
-size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix, bool runtime) {
-    return ((size_t)rr_lds_fixed_floats(R, pix, runtime) + 16 * 5 + (pixelate ? (size_t)seg_rows + 2 * R : 0)) * sizeof(float);
+size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix, bool runtime, bool glut) {
+    return ((size_t)rr_lds_fixed_floats(R, pix, runtime) + 16 * 5 + (pixelate ? (size_t)seg_rows + 2 * R : 0) + (runtime && glut ? 768 : 0)) * sizeof(float);
 }
 
 void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
@@ -259,13 +259,13 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
         if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
         for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     }
-    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, g, g).seg;   // partial last group / single frames: planned once
+    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g).seg;   // partial last group / single frames: planned once
     const int seg = c->seg_for[g];
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
     const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
     ProfEv pe(c, 0, g);
-    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, variant == 0),
+    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, variant == 0, c->kp.grade_lut != nullptr),
              s, variant, pe.e0, pe.e1);
 }
 
@@ -445,7 +445,7 @@ int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
+    for (DevBuf* b : {&c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
                       &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
@@ -485,6 +485,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         return fail(c, CRTFX_E_INVALID, "grain_size > 1 needs the grain_* resize axes");
     if ((rc = upload(c, c->triad_row, p->triad_row, (size_t)W * 3 * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_g, p->lut_g, LUT_N * sizeof(float)))) return rc;
+    const bool use_glut = p->grade_lut && c->pix_fmt == CRTFX_PIX_U8 && !(fl & CRTFX_F_SATURATION) &&
+                          (fl & (CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA));
+    if ((rc = upload(c, c->glut, use_glut ? p->grade_lut : nullptr, 3 * 256 * sizeof(float)))) return rc;
     if ((rc = upload(c, c->lut_inv, p->lut_inv, LUT_N * sizeof(float)))) return rc;
     if ((rc = upload(c, c->nx2, p->vig_nx2, (size_t)W * sizeof(double)))) return rc;
     if ((rc = upload(c, c->ny2, p->vig_ny2, (size_t)H * sizeof(double)))) return rc;
@@ -523,6 +526,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
+    k.grade_lut = use_glut ? (const float*)c->glut.p : nullptr;
     k.vig_nx2 = (const double*)c->nx2.p; k.vig_ny2 = (const double*)c->ny2.p;
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
@@ -546,7 +550,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
         const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
-        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, 1, gcap);
+        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap);
         if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) { gp.g = v; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, v); } }
         if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) gp.seg = ((v + NB - 1) / NB) * NB; }
         const int need = c->overlap ? 2 * gp.g : gp.g;

@@ -45,6 +45,7 @@ struct KParams {
     const float* __restrict__ triad_full;
     const float* __restrict__ lut_g;
     const float* __restrict__ lut_inv;
+    const float* __restrict__ grade_lut;   // [3][256]: a1 + a4 per channel and uint8 code (saturation off), or nullptr
     const double* __restrict__ vig_nx2;
     const double* __restrict__ vig_ny2;
     const double* __restrict__ vig_full;
@@ -215,8 +216,13 @@ __device__ __forceinline__ void overlay_blend_px(uint32_t px, T& v0, T& v1, T& v
 
 // a1..a4 (+ overlay-before) of one pixel of the general-purpose kernels; (y, x) in range.
 __device__ __forceinline__ void fetch_graded(const KParams& P, const KFrame& F, int y, int x, float& r, float& g, float& b) {
-    fetch_rgb(P, F.in, y, x, r, g, b);
-    grade(P, r, g, b);
+    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) {       // three table reads (L1-resident) instead of three powf
+        const RawRGB v = fetch_raw(P, F.in, y, x);
+        r = P.grade_lut[v.r]; g = P.grade_lut[256 + v.g]; b = P.grade_lut[512 + v.b];
+    } else {
+        fetch_rgb(P, F.in, y, x, r, g, b);
+        grade(P, r, g, b);
+    }
     if (F.overlay_before) overlay_blend<float>(F.overlay_before, (uint32_t)y * (uint32_t)P.W + (uint32_t)x, r, g, b);
 }
 
@@ -846,7 +852,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
     float* cringf = reinterpret_cast<float*>(cring);                        // runtime-gate build: [CR][3][TW] graded floats
     uint32_t* rowtab = cring + rr_cring_floats(R, PIX, SF == 0xFFFFFFFFu);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
-    int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);                   // [seg_rows + 2R]: source row of halo row (pixelate)
+    int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);
+    float* glut = reinterpret_cast<float*>(ytab + ((Pin.flags & CRTFX_F_PIXELATE) ? seg_rows + 2 * R : 0));   // [3][256] grade table (runtime-gate build)                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
     // prefetches).  Rotating the roles by the block's dispatch number spreads them over the SIMDs of a CU: measured
@@ -920,6 +927,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     // The overlay pixel of a staged halo position is the one at its clamped (BORDER_REPLICATE) frame position — the
     // pixelate maps do not apply to it (a3 comes before the overlay).
     const bool ovl_before = RTB && F.overlay_before != nullptr;
+    const bool use_glut = RTB && PIX == 0 && P.grade_lut != nullptr;
+    if (use_glut)
+        for (int i = tid; i < 768; i += RR_THREADS) glut[i] = P.grade_lut[i];
     uint32_t ovx[A_ITEMS], ovpx[A_ITEMS];
 #pragma unroll
     for (int u = 0; u < A_ITEMS; ++u) {
@@ -1053,8 +1063,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             const int it = tid + u * RR_THREADS;
             const int j = it / SWP, i = it - j * SWP;
             if (j < nrows) {
-                float r = norm_px(PIX, raw[u].r), g = norm_px(PIX, raw[u].g), b = norm_px(PIX, raw[u].b);
-                grade(P, r, g, b);
+                float r, g, b;
+                if (use_glut) { r = glut[raw[u].r]; g = glut[256 + raw[u].g]; b = glut[512 + raw[u].b]; }
+                else { r = norm_px(PIX, raw[u].r); g = norm_px(PIX, raw[u].g); b = norm_px(PIX, raw[u].b); grade(P, r, g, b); }
                 if (ovl_before) overlay_blend_px<float>(ovpx[u], r, g, b);
                 if (i >= pad && i < pad + TW) {     // centre column: park the pixel for C2 (graded floats, or the packed samples)
                     int cr = crow0 + j;                        // (hb + j - (y_begin - R)) % CR without the division

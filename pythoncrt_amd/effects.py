@@ -154,6 +154,9 @@ class Engine:
             flags |= _lib.F_GAMMA
             p.inv_gamma = 1.0 / float(s.gamma)
         p.saturation, p.contrast, p.brightness = float(s.saturation), float(s.contrast), float(s.brightness)
+        if self.pix_fmt == _lib.PIX_U8 and not (flags & _lib.F_SATURATION) and (flags & (_lib.F_TEMPERATURE | _lib.F_BRIGHTCON | _lib.F_GAMMA)):
+            keep["grade_lut"] = tables.grade_lut(s.brightness, s.contrast, s.gamma, s.temperature)
+            p.grade_lut = tables.ptr(keep["grade_lut"])
         if s.pixel_size > 1:
             flags |= _lib.F_PIXELATE
             keep["xmap"], keep["ymap"] = tables.pixelate_maps(h, w, s.pixel_size)

@@ -132,6 +132,26 @@ def scanline_plane(h: int, w: int, strength: float, period_px: float, phase_px: 
     return np.ascontiguousarray((1.0 - float(strength) * np.power(s, 1.0 / sharp)).astype(np.float32))
 
 
+def grade_lut(brightness: float, contrast: float, gamma: float, temperature: float) -> np.ndarray:
+    """a1 + a4 for every uint8 code and channel when saturation == 1 (the only stage of apply_color_adjustments that
+    mixes channels, ref:288-290): (3, 256) float32, lut[c, u] = value of channel c of a pixel whose sample is u after
+    ref:569 (u / 255.0) and ref:292-304, computed with the reference's own expressions on a 1 x 256 x 3 image."""
+    v = np.arange(256, dtype=np.uint8).astype(np.float32) / 255.0                         # ref:569
+    img = np.ascontiguousarray(np.repeat(v[None, :, None], 3, axis=2))                    # 1 x 256 x 3
+    if temperature != 0.0:                                                                # ref:292-297
+        t = float(temperature)
+        r_gain = float(np.clip(1.0 + 0.5 * t, 0.5, 1.5))
+        b_gain = float(np.clip(1.0 - 0.5 * t, 0.5, 1.5))
+        img[:, :, 0] = np.clip(img[:, :, 0] * r_gain, 0.0, 1.0)
+        img[:, :, 2] = np.clip(img[:, :, 2] * b_gain, 0.0, 1.0)
+    if brightness != 0.0 or contrast != 1.0:                                              # ref:299-300
+        img = np.clip((img - 0.5) * float(contrast) + 0.5 + float(brightness), 0.0, 1.0)
+    if gamma != 1.0 and gamma > 0.0:                                                      # ref:302-304
+        img = np.clip(np.power(img, 1.0 / float(gamma), dtype=np.float32), 0.0, 1.0)
+    assert img.dtype == np.float32
+    return np.ascontiguousarray(img[0].T)                                                 # (3, 256)
+
+
 def scanline_plane_scalars(period_px: float, angle_deg: float, thickness: float):
     """(omega, tan(theta), 1/sharp) of make_scanline_mask_2d exactly as ref:319-324 computes them: the scalar
     arguments of crtfx_scanline_plane."""

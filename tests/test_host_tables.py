@@ -35,7 +35,7 @@ def test_struct_layout_matches_header(lib):
     p = _lib.CrtfxParams()
     p.size = ctypes.sizeof(_lib.CrtfxParams) - 4
     assert lib.crtfx_set_params(None, ctypes.byref(p)) == _lib.E_INVALID
-    assert ctypes.sizeof(_lib.CrtfxParams) == 288 and ctypes.sizeof(_lib.CrtfxFrame) == 80   # == sizeof in C (gcc on include/crtfx.h)
+    assert ctypes.sizeof(_lib.CrtfxParams) == 296 and ctypes.sizeof(_lib.CrtfxFrame) == 80   # == sizeof in C (gcc on include/crtfx.h)
 
 
 def test_create_without_gpu_fails_cleanly(lib):

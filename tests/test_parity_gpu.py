@@ -823,3 +823,19 @@ def test_engine_cache_is_bounded(pc):
     assert len(effects._tls.engines) <= effects._ENGINES_PER_THREAD
     assert (torch.cuda.current_device(), 20, 30, 0) not in effects._tls.engines       # evicted ...
     assert np.array_equal(pc.apply_static_effects(*a(first)), ref)                    # ... and rebuilt on demand
+
+
+@pytest.mark.parametrize("grade", [dict(gamma=1.8), dict(gamma=0.6, brightness=0.04, contrast=1.15), dict(temperature=0.6, gamma=2.2),
+                                   dict(temperature=-0.8, brightness=-0.05, contrast=0.9)])
+@pytest.mark.parametrize("sigma", [0.0, 1.2, 3.0])
+def test_grade_table_paths(pc, grade, sigma):
+    """uint8 frames with the saturation mix off: a1 + a4 come from the 3 x 256 table built with the reference's numpy
+    expressions (register-window kernel: LDS copy; pointwise kernels with --gamma: L1 reads).  Bit-exact without gamma;
+    with gamma the table holds numpy's own powf values, compared at the usual 3e-7."""
+    frame = make_frame(70, 130, seed=120)
+    cfg = dict(aberration_px=1, bloom_sigma=sigma, bloom_strength=0.25 if sigma > 0 else 0.0, scanline_strength=0.6, scanline_phase_px=2.0)
+    got, exp = run_both(pc, frame, cfg, **grade)
+    if "gamma" in grade:
+        assert np.abs(got - exp.astype(np.float32)).max() <= 3e-7
+    else:
+        assert_bit_exact(got, exp)
