@@ -52,6 +52,11 @@ class FrameShard:
         chunks = (n_frames + self.chunk - 1) // self.chunk
         return (chunks + self.world - 1) // self.world
 
+    def active_ranks(self, round_index: int, n_frames: int) -> int:
+        """Ranks that own a (possibly short) chunk in this round of an n_frames clip: world, except in a partial last round."""
+        chunks = (n_frames + self.chunk - 1) // self.chunk
+        return max(0, min(self.world, chunks - round_index * self.world))
+
     def my_chunks(self, n_frames: int) -> List[Tuple[int, int]]:
         return [r for r in (self.frame_range(i, n_frames) for i in range(self.rounds(n_frames))) if r[1] > r[0]]
 
@@ -95,34 +100,49 @@ class ShardedRender:
                 r.wait()
         return recv
 
-    def run_round(self, frames: torch.Tensor, round_index: int, has_frames: bool = True):
-        """frames: this rank's chunk for this round.  Returns the finished uint8 frames."""
+    def run_round(self, frames: Optional[torch.Tensor], round_index: int, active: Optional[int] = None):
+        """frames: this rank's chunk for this round (None when it owns none).  `active` = how many ranks own a chunk in
+        this round (default: all; fewer only in the last round of a clip that is not a multiple of world * chunk frames —
+        every rank must pass the same value, see `active_ranks`).  The last chunk of the clip may be shorter than
+        `chunk`.  Returns the finished uint8 frames (None for a rank without a chunk)."""
         sh, p = self.shard, self.p
+        w, r = sh.world, sh.rank
+        a = w if active is None else int(active)
+        if not (1 <= a <= w):
+            raise ValueError(f"active = {a} outside 1..{w}")
+        has_frames = frames is not None and frames.shape[0] > 0 and r < a
         c = sh.chunk_of(round_index)
         first = c * sh.chunk
-        if not has_frames:
-            raise NotImplementedError("every rank must own a chunk in every round (pad the clip to world*chunk frames)")
-        w, r = sh.world, sh.rank
         if w == 1 and p > 0.0 and hasattr(self.engine, "sequential_scan"):
             # one rank owns consecutive chunks: carry the state itself (the reference's in-order loop, ref:1081-1105),
             # no zero-state scan and no correction pass
             out, self.carry_next_round = self.engine.sequential_scan(frames, first, None if c == 0 else self.carry_next_round)
             return out
+        if not has_frames:
+            # a partial last round: nothing to render here, and nobody downstream waits for this rank's state
+            # (the exchange below is only between ranks < active, and there is no next round to seed)
+            return None
         local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
         if p <= 0.0:
             return out
         n = frames.shape[0]
         final_local = local[n - 1]
+        full = a == w                       # a full round also seeds rank 0 for the next round
         carry = None
         if w == 1:
             carry = self.carry_next_round
             true_final = final_local if carry is None else final_local + (p ** n) * carry
             self.carry_next_round = true_final.clone()
         elif self.parallel_hop:
-            # every rank forwards its chunk-final local state (== true state to float32 rounding)
-            got = self._send_recv(final_local, final_local, (r - 1) % w, (r + 1) % w)
+            # every rank forwards its chunk-final local state (== true state to float32 rounding; only full-length
+            # chunks ever send: a short chunk is the last of the clip)
+            dst = (r + 1) % w if (full or r + 1 < a) else None
+            src = (r - 1) % w if (full or r > 0) else None
+            got = self._send_recv(final_local if dst is not None else None, final_local, src, dst)
             if r == 0:
-                carry, self.carry_next_round = self.carry_next_round, got      # what arrived now seeds the next round
+                carry = self.carry_next_round
+                if full:
+                    self.carry_next_round = got      # what arrived now seeds the next round
             else:
                 carry = got
             if c == 0:
@@ -132,12 +152,15 @@ class ShardedRender:
             if r == 0:
                 carry = None if c == 0 else self.carry_next_round
                 true_final = final_local if carry is None else final_local + (p ** n) * carry
-                self._send_recv(true_final, final_local, None, 1)
-                self.carry_next_round = self._send_recv(None, final_local, w - 1, None)
+                if a > 1:
+                    self._send_recv(true_final, final_local, None, 1)
+                if full:
+                    self.carry_next_round = self._send_recv(None, final_local, w - 1, None)
             else:
                 carry = self._send_recv(None, final_local, r - 1, None)
                 true_final = final_local + (p ** n) * carry
-                self._send_recv(true_final, final_local, None, (r + 1) % w)
+                if full or r + 1 < a:
+                    self._send_recv(true_final, final_local, None, (r + 1) % w)
         if carry is not None:
             self.engine.correct(local, carry, p, out)
         return out

@@ -77,6 +77,42 @@ def free_port():
     return port
 
 
+def ragged_worker(rank, world, port, p, chunk, n_frames, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = clip_frames(n_frames)
+    shard = FrameShard(world, rank, chunk)
+    render = ShardedRender(shard, p, OracleEngine(p), dist=dist)
+    for r in range(shard.rounds(n_frames)):
+        lo, hi = shard.frame_range(r, n_frames)
+        mine = torch.from_numpy(np.stack(frames[lo:hi])) if hi > lo else None
+        out = render.run_round(mine, r, active=shard.active_ranks(r, n_frames))
+        assert (out is None) == (hi == lo)
+        if out is not None:
+            np.save(os.path.join(outdir, f"out_{lo}.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p,chunk,n_frames", [(0.5, 3, 14), (0.5, 26, 60), (0.9, 5, 11), (0.0, 4, 9), (0.6, 4, 4)])
+def test_two_rank_render_of_a_ragged_clip(tmp_path, p, chunk, n_frames):
+    """The clip is not a multiple of world * chunk frames: the last round is owned by one rank only and / or its
+    chunk is short.  Both the parallel-hop (p^B < 2^-24) and the exact ring chain are exercised."""
+    world = 2
+    mp.spawn(ragged_worker, args=(world, free_port(), p, chunk, n_frames, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out_{lo}.npy") for lo in range(0, n_frames, chunk)])
+    frames = clip_frames(n_frames)
+    state, exp = None, []
+    for i, f in enumerate(frames):
+        state, u8 = orc.persistence_blend(state, static_of(f, i), p)
+        exp.append(u8)
+    exp = np.stack(exp)
+    assert got.shape == exp.shape
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
+
+
 @pytest.mark.parametrize("p,chunk,rounds", [(0.5, 3, 3), (0.5, 26, 2), (0.9, 5, 2), (0.0, 4, 2)])
 def test_two_rank_render_matches_sequential(tmp_path, p, chunk, rounds):
     world = 2
@@ -101,6 +137,7 @@ def test_shard_plan():
     assert sh.owner(0) == 0 and sh.owner(16 * 3) == 3 and sh.owner(16 * 11 + 5) == 3
     assert sh.frame_range(0) == (48, 64) and sh.frame_range(1) == (176, 192)
     assert sh.my_chunks(16 * 8 * 2) == [(48, 64), (176, 192)]
+    assert sh.active_ranks(0, 300) == 8 and sh.active_ranks(2, 300) == 3 and sh.active_ranks(1, 16 * 8 * 2) == 8 and sh.rounds(300) == 3
     covered = sorted(t for r in range(8) for lo, hi in FrameShard(8, r, 16).my_chunks(300) for t in range(lo, hi))
     assert covered == list(range(300))
     assert settle_frames(0.5) == 24 and settle_frames(0.95) == 325 and settle_frames(0.0) == 0
