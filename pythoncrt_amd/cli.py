@@ -131,8 +131,79 @@ def _read_into(fin, view: memoryview) -> int:
     return got
 
 
+def main_sharded(a, rank: int, world: int) -> int:
+    """One process per GPU (launched with `python -m torch.distributed.run --nproc-per-node N -m pythoncrt_amd.cli ...`):
+    the clip's chunks of --batch frames are dealt round-robin over the ranks, each rank reads its chunks
+    from the raw input file and writes them at the same offsets of the output file; with --persistence > 0 one
+    float32 state frame per chunk boundary travels to the next rank (RCCL)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from .pipeline import FramePipeline, GpuShardEngine
+    from .shard import FrameShard, ShardedRender
+    from .text import make_text_overlay_rgba
+    if a.input == "-" or not a.output or a.output == "-":
+        raise SystemExit("the sharded CLI needs seekable --input and --output files")
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm device visible; pythoncrt_amd has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl" if ndev >= world else "gloo")     # gloo: rehearsal of N ranks on fewer GPUs
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    rs = settings_from_args(a)
+    fps_out = int(a.fps) if a.fps and a.fps > 0 else 24
+    h, w = int(a.height), int(a.width)
+    box = [a.noise_seed if a.noise_seed is not None else int.from_bytes(os.urandom(8), "little")]
+    dist.broadcast_object_list(box, src=0)               # every rank draws the same grain stream
+    overlay = make_text_overlay_rgba(w, h, a.text, a.text_font, a.text_size, a.text_color, (a.text_x, a.text_y)) if a.text else None
+    pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=box[0], text_overlay_rgba=overlay, text_overlay_after=bool(a.text_after))
+    B = max(1, int(a.batch))
+    frame_bytes = h * w * 3
+    n_frames = os.path.getsize(a.input) // frame_bytes
+    shard = FrameShard(world, rank, B)
+    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B), dist=dist)
+    if rank == 0:
+        with open(a.output, "wb") as f:
+            f.truncate(n_frames * frame_bytes)
+    dist.barrier()
+    t0 = time.perf_counter()
+    fin, fout = os.open(a.input, os.O_RDONLY), os.open(a.output, os.O_WRONLY)
+    host = torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory()
+    done = 0
+    for r in range(shard.rounds(n_frames)):
+        lo, hi = shard.frame_range(r, n_frames)
+        frames = None
+        if hi > lo:
+            view = memoryview(host.numpy()).cast("B")[: (hi - lo) * frame_bytes]
+            got = 0
+            while got < len(view):
+                k = os.preadv(fin, [view[got:]], lo * frame_bytes + got)
+                if k <= 0:
+                    raise SystemExit(f"short read at frame {lo}")
+                got += k
+            frames = host[: hi - lo].to(dev, non_blocking=True)
+        out = render.run_round(frames, r, active=shard.active_ranks(r, n_frames))
+        if out is not None:
+            buf = out.cpu().numpy().tobytes()
+            os.pwrite(fout, buf, lo * frame_bytes)
+            done += hi - lo
+    os.close(fin); os.close(fout)
+    dist.barrier()
+    print(f"rank {rank}: {done} of {n_frames} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)
+    dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None) -> int:
     a = build_parser().parse_args(argv)
+    import os as _os
+    if int(_os.environ.get("WORLD_SIZE", "1")) > 1:
+        if a.gui or not a.input or a.width <= 0 or a.height <= 0:
+            raise SystemExit("pass --input, --width and --height")
+        return main_sharded(a, int(_os.environ.get("RANK", "0")), int(_os.environ["WORLD_SIZE"]))
     if a.gui or not a.input:
         raise SystemExit("the GUI is not part of this path; pass --input (raw rgb24 file or '-')")
     if a.width <= 0 or a.height <= 0:

@@ -90,15 +90,18 @@ class ShardedRender:
     def _send_recv(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
         ops, recv = [], None
         d = self.dist
+        # RCCL moves device tensors directly (one xGMI hop).  gloo has no device point-to-point: stage through the
+        # host (CPU tests, and rehearsals of several ranks on one GPU).
+        stage = recv_like.is_cuda and d.get_backend(self.group) == "gloo"
         if dst is not None and send is not None:
-            ops.append(d.P2POp(d.isend, send.contiguous(), dst, self.group))
+            ops.append(d.P2POp(d.isend, send.cpu() if stage else send.contiguous(), dst, self.group))
         if src is not None:
-            recv = torch.empty_like(recv_like)
+            recv = torch.empty_like(recv_like, device="cpu") if stage else torch.empty_like(recv_like)
             ops.append(d.P2POp(d.irecv, recv, src, self.group))
         if ops:
             for r in d.batch_isend_irecv(ops):
                 r.wait()
-        return recv
+        return recv.to(recv_like.device) if (stage and recv is not None) else recv
 
     def run_round(self, frames: Optional[torch.Tensor], round_index: int, active: Optional[int] = None):
         """frames: this rank's chunk for this round (None when it owns none).  `active` = how many ranks own a chunk in

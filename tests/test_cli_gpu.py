@@ -105,3 +105,38 @@ def test_overlay_of_another_size_matches_reference(pc):
                                       text_overlay_rgba=ov, text_overlay_after=after)
         exp = tg[f"fit/static_after{int(after)}"]
         assert got.shape == exp.shape and np.array_equal(got, exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("persistence,n_frames", [("0.5", 11), ("0", 9)])
+def test_sharded_cli_two_ranks(pc, tmp_path, persistence, n_frames):
+    """SURVEY 8e end to end: two ranks (one process each, launched by torch.distributed.run; both on this box's single
+    GPU, so the state frame is exchanged through gloo's host staging instead of RCCL) render a ragged clip from a raw
+    file into a raw file; the bytes must be the single-process render's (exactly without persistence, <= 1 LSB with
+    the p^j carry correction)."""
+    import socket
+    import subprocess
+    import sys
+    from pythoncrt_amd import cli
+    h, w = 72, 128
+    frames = clip(n_frames, h, w, 9)
+    src = tmp_path / "in.rgb"
+    src.write_bytes(frames.tobytes())
+    flags = ["--width", str(w), "--height", str(h), "--fps", "30", "--batch", "3", "--noise-seed", "7", "--persistence", persistence,
+             "--no-fast-bloom", "--bloom-sigma", "1.2", "--warp-strength", "0.15", "--pixel-size", "1"]
+    one = tmp_path / "one.rgb"
+    assert cli.main(["--input", str(src), "--output", str(one)] + flags) == 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = tmp_path / "two.rgb"
+    env = dict(os.environ, CRTFX_DIST_BACKEND="gloo", PYTHONPATH=os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "pythoncrt_amd.cli", "--input", str(src), "--output", str(two)] + flags
+    r = subprocess.run(cmd, env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = np.frombuffer(one.read_bytes(), dtype=np.uint8)
+    b = np.frombuffer(two.read_bytes(), dtype=np.uint8)
+    assert a.size == b.size == frames.size
+    if persistence == "0":
+        assert np.array_equal(a, b)
+    else:
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
