@@ -101,13 +101,14 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl")      # "gloo": rehearsal of several ranks on fewer GPUs (never a result)
+    device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
     from pythoncrt_amd.pipeline import FramePipeline, GpuShardEngine, baseline_config
     from pythoncrt_amd.shard import FrameShard, ShardedRender
