@@ -31,7 +31,7 @@ struct crtfx_ctx {
     int pix_fmt = CRTFX_PIX_U8;
     bool params_set = false;
     KParams kp{};
-    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut;
+    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
@@ -382,6 +382,10 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
                           !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane && !kf.overlay_before && c->kp.grain <= 1 &&
                           !k1.overlay_after && !k1.out_f32 && (k1.blend == CRTFX_BLEND_NONE || k1.blend == CRTFX_BLEND_RENDER);
         if (lean) launch_point_lean(c, gates == SF_FAST_PIX, k1.blend == CRTFX_BLEND_RENDER, grid, dim3(64 * waves), s, pe.e0, pe.e1, kf, k1);
+        else if (!c->force_generic && !((fl & CRTFX_F_NOISE) && c->kp.grain > 1)) {      // any gate set, loads branch-free
+            if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_F16>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
+            else { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_U8>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
+        }
         else CRTFX_LAUNCH((k_point<SF_RUNTIME>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
     }
     if (two) {
@@ -445,7 +449,7 @@ int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
+    for (DevBuf* b : {&c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
                       &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
@@ -527,6 +531,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
     k.grade_lut = use_glut ? (const float*)c->glut.p : nullptr;
+    {
+        float cst[32] = {1.0f, 1.0f, 1.0f, 1.0f};      // then zeros: the address a disabled stage loads from in k_point_sel
+        if ((rc = upload(c, c->consts, cst, sizeof(cst)))) return rc;
+        k.consts = (const float*)c->consts.p;
+    }
     k.vig_nx2 = (const double*)c->nx2.p; k.vig_ny2 = (const double*)c->ny2.p;
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;

@@ -63,6 +63,7 @@ struct KParams {
     const int* __restrict__ dy_ofs; const float* __restrict__ dy_a;
     int hw, hh;                                                         // half-res size (max(1, W//2), max(1, H//2))
     float* ds;                                                          // half-res thresholded source, hh x hw x 3 float32 (ctx scratch)
+    const float* consts;                                                // ctx-owned: float 1,1,1,1 then 112 zero bytes — a valid address for loads a disabled stage would make (k_point_sel)
 };
 
 struct KFrame {
@@ -566,6 +567,111 @@ __global__ __launch_bounds__(1024) void k_point(KParams Pin, KFrame F, KOut O) {
         }
     }
     emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
+}
+
+// k_point_sel — the pointwise chain for ANY gate set with the loads made branch-free.  hipcc ends every conditional
+// block that contains a load with an s_waitcnt vmcnt(0), so the gate-by-gate k_point above pays one memory round trip
+// per enabled stage (eight in a row for the reference CLI's defaults with one knob changed).  Here every stage's
+// address is a wave-uniform SELECT between its real table and a small constant buffer (ones / zeros), the loads are
+// issued unconditionally in two groups (tables and planes; then the samples and half-res taps that need the index
+// tables) and the stage arithmetic is gated afterwards (branches without loads cost nothing).  Same arithmetic, same bits as k_point (test_kernel_variants_agree); grain_size > 1 stays on k_point.
+template <typename T>
+__device__ __forceinline__ void point_finish(const KParams& P, const KFrame& F, const KOut& O, int y, int x, uint32_t pix, bool row_live,
+                                             const PixMasks& M, float r, float g, float b, const float* lut, uint32_t ov_after, F3 st,
+                                             int x0, int lane) {
+    T v0, v1, v2;
+    tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v0, v1, v2);
+    if (O.pre) {                                 // two-kernel path: park the pre-warp pixel for k_warp
+        if (row_live) *reinterpret_cast<F3*>(O.pre + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
+        return;
+    }
+    if (O.overlay_after) overlay_blend_px<T>(ov_after, v0, v1, v2);      // the pixel was loaded above; no load inside this branch
+    if (O.out_f32 && row_live) *reinterpret_cast<F3*>(O.out_f32 + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
+    const T p = (T)O.p, q = (T)O.q;
+    if (O.blend == CRTFX_BLEND_RENDER) {          // ref:1092
+        v0 = clip01(p * (T)st.x + q * v0); v1 = clip01(p * (T)st.y + q * v1); v2 = clip01(p * (T)st.z + q * v2);
+    } else if (O.blend == CRTFX_BLEND_PREVIEW) {  // ref:693 addWeighted = fma(prev, a, img*b)
+        if constexpr (sizeof(T) == 8) { v0 = fma((T)st.x, p, v0 * q); v1 = fma((T)st.y, p, v1 * q); v2 = fma((T)st.z, p, v2 * q); }
+        else { v0 = fmaf(st.x, p, v0 * q); v1 = fmaf(st.y, p, v1 * q); v2 = fmaf(st.z, p, v2 * q); }
+    }
+    const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
+    if (O.state && row_live) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
+    if (O.out_u8 && row_live) {
+        PackedPix pk;
+        if (O.pix == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+        else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+        store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), pk);
+    }
+}
+
+template <int PIX>
+__global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut Oin) {
+    __shared__ float lut[2 * LUT_STRIDE];
+    KParams P = Pin;
+    P.pix = PIX; P.grain = 1;
+    KOut O = Oin;
+    O.pix = PIX;
+    const uint32_t fl = P.flags;
+    const float* ones = P.consts;
+    const float* zf = P.consts + 4;
+    const int* zi = reinterpret_cast<const int*>(zf);
+    const double* zd = reinterpret_cast<const double*>(zf);
+    const uint32_t* zu = reinterpret_cast<const uint32_t*>(zf);
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int yraw = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool row_live = yraw < P.H;              // wave-uniform; rows past the bottom redo the last row without storing
+    const int y = min(yraw, P.H - 1);
+    const int x = min(x0 + lane, P.W - 1);         // lanes past the right edge redo the last pixel: same values, same stores
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+    // ---- group 1: loads whose addresses need no other load --------------------------------------------------
+    const bool pxl = (fl & CRTFX_F_PIXELATE) != 0;
+    const int xm = *(pxl ? P.xmap + x : zi), ym = *(pxl ? P.ymap + y : zi);
+    const bool fb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
+    const int ux = *(fb ? P.ux_ofs + x : zi), uy = *(fb ? P.uy_ofs + y : zi);
+    const float ua = *(fb ? P.ux_a + x : zf), ub = *(fb ? P.uy_a + y : zf);
+    const bool tri = (fl & CRTFX_F_TRIAD) != 0;
+    const F3 tm = *reinterpret_cast<const F3*>(tri ? (P.triad_full ? P.triad_full + (size_t)pix * 3 : P.triad_row + x * 3) : ones);
+    const float sl = *((fl & CRTFX_F_SCANLINES) ? (F.scan_plane ? F.scan_plane + pix : F.scan_row + y) : ones);
+    const bool vg = (fl & CRTFX_F_VIGNETTE) != 0, vfull = vg && P.vig_full != nullptr;
+    const double vfv = *(vfull ? P.vig_full + pix : zd);
+    const double nx2 = *((vg && !vfull) ? P.vig_nx2 + x : zd), ny2 = *((vg && !vfull) ? P.vig_ny2 + y : zd);
+    const uint32_t ov_before = *(F.overlay_before ? reinterpret_cast<const uint32_t*>(F.overlay_before) + pix : zu);
+    const uint32_t ov_after = *(O.overlay_after ? reinterpret_cast<const uint32_t*>(O.overlay_after) + pix : zu);
+    const float* sin = O.state_in ? O.state_in : O.state;
+    const F3 st = *reinterpret_cast<const F3*>((O.blend != CRTFX_BLEND_NONE) ? sin + (size_t)pix * 3 : zf);
+    const float zn = *(F.noise_plane ? F.noise_plane + pix : zf);
+    if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT))
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    // ---- group 2: the samples (through the pixelate maps) and the half-res taps (through the upsample axes) ------
+    const int xs = pxl ? xm : x, ys = pxl ? ym : y;
+    int xr = xs, xb = xs;
+    if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }      // ref:573-575
+    const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
+    const RawRGB raw = load_raw(PIX, F.in, row + (uint32_t)xr * 3u, row + (uint32_t)xs * 3u + 1u, row + (uint32_t)xb * 3u + 2u);
+    const int hw = fb ? P.hw : 1, hh = fb ? P.hh : 1;
+    const float* dsb = fb ? P.ds : zf;
+    const int ux1 = min(ux + 1, hw - 1), uy1 = min(uy + 1, hh - 1);
+    const F3 p00 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux) * 3);
+    const F3 p01 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux1) * 3);
+    const F3 p10 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux) * 3);
+    const F3 p11 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux1) * 3);
+    __syncthreads();                               // LUTs visible (every thread of the block gets here)
+    // ---- arithmetic, gated ----------------------------------------------------------------------------------------
+    float r, g, b;
+    if (P.grade_lut && (fl & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+    if (F.overlay_before) overlay_blend_px<float>(ov_before, r, g, b);     // the pixel was loaded above; no load inside this branch
+    if (fb) {
+        const float a1 = ua, a0 = 1.0f - a1, b1 = ub, b0 = 1.0f - b1;
+        const float bl0 = (p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1;
+        const float bl1 = (p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1;
+        const float bl2 = (p00.z * a0 + p01.z * a1) * b0 + (p10.z * a0 + p11.z * a1) * b1;
+        r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+    }
+    PixMasks M{tm.x, tm.y, tm.z, sl, vfull ? vfv : vignette_gain(P, nx2, ny2), zn, F.noise_plane != nullptr};
+    if (promotes(P)) point_finish<double>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
+    else point_finish<float>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
 }
 
 // k_point_lean — k_point for a plain render frame: gate word, pixel format and blend mode are compile-time, no
