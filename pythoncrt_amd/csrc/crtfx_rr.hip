@@ -19,11 +19,13 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else {
         if (lds > 65536) {      // large radii park up to 35 KB of graded centre pixels: above the default dynamic-LDS limit
-            static bool raised = false;
-            if (!raised) {
+            static bool raised[64] = {};      // per device: one process may drive several GPUs
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64 || !raised[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                raised = true;
+                if (dev >= 0 && dev < 64) raised[dev] = true;
             }
         }
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
