@@ -13,12 +13,13 @@
  *     tensor.data_ptr()); the library never frees or retains them beyond the stream work it
  *     enqueues.  Host tables passed to crtfx_set_params are copied before it returns.
  *   - all device work is enqueued on the caller's hipStream_t (passed as void*, NULL = the
- *     default stream); no entry point except create/destroy/set_params synchronises.
+ *     default stream); no entry point except create/destroy/set_params synchronises.  The calling
+ *     thread's current HIP device must be the ctx's device (CRTFX_E_INVALID otherwise).
  *   - one ctx per (device, frame size, caller thread).  Distinct ctxs may be used concurrently
  *     (the reference calls apply_static_effects from 2 worker threads, ref:1015-1017, and
  *     apply_crt_effect from the GUI thread, ref:1810).
  *   - frames are H x W x 3 interleaved RGB, C-contiguous: uint8 (ref:489,502,1036) or, for
- *     CRTFX_PIX_F16, IEEE half with values in [0,1].  Float images / state are float32 H x W x 3.
+ *     CRTFX_PIX_F16, IEEE half on the same 0..255 scale.  Float images / state are float32 H x W x 3.
  */
 #ifndef CRTFX_H
 #define CRTFX_H

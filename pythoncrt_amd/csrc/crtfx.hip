@@ -405,6 +405,15 @@ int check_blend(crtfx_ctx* c, int blend, double p, const float* state) {
     return CRTFX_OK;
 }
 
+// Launches go to the calling thread's CURRENT device (as with any stream-taking HIP library); refuse loudly when
+// that is not the device the ctx (its scratch, tables and the caller's stream) lives on.
+int check_device(crtfx_ctx* c) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(c, CRTFX_E_HIP, "hipGetDevice failed");
+    if (dev != c->device) return fail(c, CRTFX_E_INVALID, "current device %d is not the ctx's device %d (call hipSetDevice first)", dev, c->device);
+    return CRTFX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -587,6 +596,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
 
 int crtfx_apply_static(crtfx_ctx* c, const void* frame_dev, float* out_float_dev, const crtfx_frame* frame, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!out_float_dev) return fail(c, CRTFX_E_INVALID, "out_float_dev is NULL");
     KOut ko{};
     ko.out_f32 = out_float_dev;
@@ -597,6 +607,7 @@ int crtfx_apply_static(crtfx_ctx* c, const void* frame_dev, float* out_float_dev
 int crtfx_apply(crtfx_ctx* c, const void* frame_dev, void* out_pix_dev, float* state_inout_dev, float* out_float_dev,
                 int blend, double persistence, const crtfx_frame* frame, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     int rc = check_blend(c, blend, persistence, state_inout_dev);
     if (rc) return rc;
     if (!out_pix_dev && !state_inout_dev && !out_float_dev) return fail(c, CRTFX_E_INVALID, "no output requested");
@@ -612,6 +623,7 @@ int crtfx_apply(crtfx_ctx* c, const void* frame_dev, void* out_pix_dev, float* s
 int crtfx_blend_quantise(crtfx_ctx* c, const float* static_dev, float* state_inout_dev, void* out_pix_dev, int blend,
                          double persistence, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!static_dev) return fail(c, CRTFX_E_INVALID, "static_dev is NULL");
     int rc = check_blend(c, blend, persistence, state_inout_dev);
     if (rc) return rc;
@@ -631,6 +643,7 @@ int crtfx_blend_quantise(crtfx_ctx* c, const float* static_dev, float* state_ino
 int crtfx_halo_correct_quantise(crtfx_ctx* c, const float* local_dev, const float* carry_in_dev, double coeff,
                                 float* state_out_dev, void* out_pix_dev, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!local_dev || !carry_in_dev) return fail(c, CRTFX_E_INVALID, "local_dev / carry_in_dev is NULL");
     KOut ko{};
     ko.out_u8 = static_cast<uint8_t*>(out_pix_dev);
@@ -648,6 +661,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         size_t out_stride_bytes, int n, const crtfx_frame* frames, float* state_inout_dev,
                         double persistence, int first_has_state, float* local_states_base, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (n < 0 || !frames_base || (!out_base && !local_states_base)) return fail(c, CRTFX_E_INVALID, "bad batch arguments");
     if (persistence > 0.0 && !state_inout_dev) return fail(c, CRTFX_E_INVALID, "persistence > 0 needs state_inout_dev");
     if (local_states_base && !(persistence > 0.0)) return fail(c, CRTFX_E_INVALID, "local_states_base needs persistence > 0");
@@ -745,6 +759,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
 
 int crtfx_noise_plane(crtfx_ctx* c, uint64_t seed, uint64_t frame_index, float* out_dev, void* stream) {
     if (!c || !out_dev) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     uint32_t k0, k1;
     noise_keys(seed, frame_index, k0, k1);
     const int n = c->H * c->W;
@@ -755,6 +770,7 @@ int crtfx_noise_plane(crtfx_ctx* c, uint64_t seed, uint64_t frame_index, float* 
 
 int crtfx_warp_map(crtfx_ctx* c, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_dev, void* stream) {
     if (!c || !ix_dev || !iy_dev || !fxy_dev) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!c->params_set || !(c->kp.flags & CRTFX_F_WARP)) return fail(c, CRTFX_E_INVALID, "warp is not enabled in the current params");
     hipLaunchKernelGGL(k_warp_map, dim3((c->W + 255) / 256, c->H), dim3(256), 0, (hipStream_t)stream, c->kp, ix_dev, iy_dev, fxy_dev);
     HIP_TRY(c, hipGetLastError());
@@ -764,6 +780,7 @@ int crtfx_warp_map(crtfx_ctx* c, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_
 int crtfx_scanline_plane(crtfx_ctx* c, double strength, double omega, double phase_px, double tan_theta, double inv_sharp,
                          float* out_dev, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!out_dev) return fail(c, CRTFX_E_INVALID, "out_dev is NULL");
     hipLaunchKernelGGL(k_scan_plane, dim3((c->W + 255) / 256, c->H), dim3(256), 0, (hipStream_t)stream, c->H, c->W, strength, omega,
                        phase_px, tan_theta, inv_sharp, out_dev);
@@ -773,6 +790,7 @@ int crtfx_scanline_plane(crtfx_ctx* c, double strength, double omega, double pha
 
 int crtfx_resize_state(crtfx_ctx* c, const float* src_dev, int src_h, int src_w, float* dst_dev, void* stream) {
     if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
     if (!src_dev || !dst_dev || src_h <= 0 || src_w <= 0) return fail(c, CRTFX_E_INVALID, "bad resize arguments");
     if (!c->params_set) return fail(c, CRTFX_E_INVALID, "crtfx_set_params has not been called");
     if (src_h > 32767 || src_w > 32767) return fail(c, CRTFX_E_UNSUPPORTED, "state of %dx%d exceeds 32767", src_w, src_h);
