@@ -140,3 +140,35 @@ def test_sharded_cli_two_ranks(pc, tmp_path, persistence, n_frames):
     else:
         d = np.abs(a.astype(np.int16) - b.astype(np.int16))
         assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
+
+
+def test_c_abi_consumer(pc, tmp_path):
+    """examples/crtfx_c_abi.cpp: a program that uses only include/crtfx.h, libcrtfx.so and the HIP runtime (no Python
+    or torch in its call path; it builds the vignette and warp axis tables itself) renders the same bytes as the Python
+    host with the same settings."""
+    import shutil
+    import subprocess
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "build", "crtfx_c_abi")
+    src = os.path.join(root, "examples", "crtfx_c_abi.cpp")
+    lib = os.path.join(root, "pythoncrt_amd", "libcrtfx.so")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), src, "-L" + os.path.dirname(lib), "-lcrtfx",
+                        "-o", exe], check=True, timeout=300)
+    n, h, w = 5, 72, 128
+    frames = clip(n, h, w, 11)
+    fin, fout = tmp_path / "in.rgb", tmp_path / "out.rgb"
+    fin.write_bytes(frames.tobytes())
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(lib) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, str(fin), str(w), str(h), str(n), str(fout)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "frames of 128x72" in r.stdout
+    got = np.frombuffer(fout.read_bytes(), dtype=np.uint8).reshape(n, h, w, 3)
+    rs = RenderSettings(scanline_strength=0.0, triad_strength=0.0, aberration_px=2, bloom_strength=0.0, noise_strength=0.0,
+                        vignette_strength=0.4, persistence=0.5, fast_bloom=False, pixel_size=1, warp_strength=0.2)
+    pipe = FramePipeline(torch.device("cuda", 0), h, w, rs, fps=30.0, noise_seed=0)
+    exp, _ = pipe.run(torch.from_numpy(frames).cuda())
+    assert np.array_equal(got, exp.cpu().numpy())
