@@ -187,9 +187,9 @@ struct GridPlan { int g, seg; };
 GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed) {
     const int strips = (W + TW - 1) / TW;
     const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
-    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded && pix != CRTFX_PIX_F16, glut);
+    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
     int bpc = (int)(163840 / lds);
-    const int by_regs = rr_min_waves(Rk, folded || pix == CRTFX_PIX_F16);      // a block = one wave per SIMD
+    const int by_regs = rr_min_waves(Rk, folded);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
     const int slots = bpc * 256;
     const int hcap = ((H + NB - 1) / NB) * NB;
@@ -244,8 +244,9 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
     // a per-pixel scanline plane and a coarse grain plane (grain_size > 1) are handled by the runtime-gate build only (uint8 frames)
     // (text overlays before the effects, or after them when the same kernel also commits) are handled by the runtime-gate build only
     const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) || kf.overlay_before || ko.overlay_after;
+    (void)folded; (void)needs_runtime;      // both pixel formats have a gate-folded and a runtime-gate build
     return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
-           ko.blend == CRTFX_BLEND_NONE && (c->pix_fmt != CRTFX_PIX_F16 || (folded && !needs_runtime));
+           ko.blend == CRTFX_BLEND_NONE;
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
@@ -255,17 +256,16 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
 #undef CRTFX_RR_ENTRY
     const int R = c->kp.R;
     bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
-    if (c->pix_fmt != CRTFX_PIX_F16) {
-        if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
-        for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
-    }
+    if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
+    for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g).seg;   // partial last group / single frames: planned once
     const int seg = c->seg_for[g];
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const int variant = c->pix_fmt == CRTFX_PIX_F16 ? 2 : (folded ? 1 : 0);
+    const int variant = c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0);
+    const bool runtime = !folded;
     ProfEv pe(c, 0, g);
-    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, variant == 0, c->kp.grade_lut != nullptr),
+    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr),
              s, variant, pe.e0, pe.e1);
 }
 

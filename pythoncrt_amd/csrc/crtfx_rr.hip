@@ -17,6 +17,19 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else if (variant == 1)
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    else if (variant == 3) {     // half frames, runtime gates
+        if (lds > 65536) {
+            static bool raised16[64] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= 64 || !raised16[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (dev >= 0 && dev < 64) raised16[dev] = true;
+            }
+        }
+        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    }
     else {
         if (lds > 65536) {      // large radii park up to 35 KB of graded centre pixels: above the default dynamic-LDS limit
             static bool raised[64] = {};      // per device: one process may drive several GPUs

@@ -571,7 +571,9 @@ def f16_frame(h, w, seed):
 
 
 @pytest.mark.parametrize("cfg", [dict(aberration_px=1), dict(FULL, bloom_sigma=3.0), dict(FULL, bloom_sigma=1.2, triad_preserve_luma=True),
-                                 dict(FULL, bloom_sigma=6.5), dict(FULL, fast_bloom=True, pixel_size=2)])
+                                 dict(FULL, bloom_sigma=6.5), dict(FULL, fast_bloom=True, pixel_size=2),
+                                 dict(FULL, noise_strength=0.0, bloom_sigma=2.0, bloom_threshold=0.2),     # runtime-gate half build of k_phosphor_rr
+                                 dict(FULL, noise_strength=0.0, bloom_sigma=5.0, triad_preserve_luma=True, pixel_size=2)])
 def test_fp16_frames(pc, cfg):
     """A float16 frame is the reference's frame array held as half (ref:569 divides whatever it gets by
     255.0); the float image is compared as for uint8 frames, the half output frame is |x*255| narrowed."""
