@@ -54,6 +54,8 @@ class TriadMask:
         return full if dtype is None else full.astype(dtype)
 
     def key(self):
+        if self.strength != self.strength:       # recognised from a plain array: identified by the row itself
+            return ("triad_row", self.h, self.w, hash(self.row.tobytes()))
         return ("triad_row", self.h, self.w, self.strength, self.softness_px)
 
 
@@ -72,6 +74,73 @@ class VignetteMask:
 
     def key(self):
         return ("vig_axes", self.h, self.w, self.strength)
+
+
+# A caller that rebinds only apply_* keeps building its masks with the reference's own make_triad_mask /
+# make_vignette and hands over H x W x 3 float32 / H x W float64 numpy arrays (99.5 MB + 66 MB at 4K).  Those have the
+# structure the descriptors encode — identical rows; 1 - s * clip(nx^2 + ny^2) — so they are recognised once per
+# array object (verified element for element, remembered by identity) and take the same fast path; anything else
+# stays a per-pixel plane.
+# The verdict is remembered per array OBJECT: the entry keeps a reference to the array (so its id cannot be reused by
+# another array while the entry lives) together with a fingerprint of a strided sample (an in-place rebuild of the
+# mask is then looked at again).  At most four arrays are held.
+_RECOGNISED = {}      # (kind, id(array)) -> (array, fingerprint, descriptor or False)
+_RECOGNISED_MAX = 4
+
+
+def _fingerprint(a: np.ndarray) -> int:
+    step = max(1, a.shape[0] // 8)
+    return hash((a.shape, a[::step, :: max(1, a.shape[1] // 64)].tobytes()))
+
+
+def _lookup(kind, mask):
+    e = _RECOGNISED.get((kind, id(mask)))
+    if e is not None and e[0] is mask and e[1] == _fingerprint(mask):
+        return e[2]
+    return None
+
+
+def _remember(kind, mask, value):
+    _RECOGNISED.pop((kind, id(mask)), None)
+    while len(_RECOGNISED) >= _RECOGNISED_MAX:
+        _RECOGNISED.pop(next(iter(_RECOGNISED)))
+    _RECOGNISED[(kind, id(mask))] = (mask, _fingerprint(mask), value)
+    return value
+
+
+def _recognise_triad(mask):
+    if not isinstance(mask, np.ndarray) or mask.ndim != 3 or mask.shape[2] != 3 or mask.dtype != np.float32 or mask.shape[0] < 1:
+        return mask
+    hit = _lookup("triad", mask)
+    if hit is None:
+        row = np.ascontiguousarray(mask[0])
+        same = bool((mask[:: max(1, mask.shape[0] // 16)] == row).all()) and bool((mask == row).all())      # cheap sample first
+        hit = _remember("triad", mask, TriadMask(mask.shape[0], mask.shape[1], float("nan"), float("nan"), row.copy()) if same else False)
+    return hit if hit else mask
+
+
+def _recognise_vignette(mask):
+    if not isinstance(mask, np.ndarray) or mask.ndim != 2 or mask.dtype != np.float64 or mask.size == 0:
+        return mask
+    hit = _lookup("vig", mask)
+    if hit is None:
+        h, w = mask.shape
+        nx2, ny2 = tables.vignette_axes(h, w)
+        found = False
+        if nx2[0] + ny2[0] >= 1.0:                       # the corner sits on the clip: v = 1 - s there
+            s0 = 1.0 - float(mask[0, 0])
+            cands = {s0, round(s0, 6), round(s0, 4), round(s0, 3), round(s0, 2)}
+            for k in range(1, 4):
+                cands.add(float(np.nextafter(s0, 2.0)) if k == 1 else float(np.nextafter(s0, -1.0)) if k == 2 else s0)
+            ys, xs = np.arange(0, h, max(1, h // 32)), np.arange(0, w, max(1, w // 32))
+            sample = mask[np.ix_(ys, xs)]
+            for s in sorted(cands):
+                if 0.0 <= s <= 1.0 and np.array_equal(sample, 1.0 - s * np.clip(nx2[None, xs] + ny2[ys, None], 0.0, 1.0)) \
+                        and np.array_equal(mask, tables.vignette_full(h, w, s)):
+                    found = VignetteMask(h, w, s)
+                    break
+        hit = _remember("vig", mask, found)
+    return hit if hit else mask
 
 
 def make_triad_mask(h: int, w: int, strength: float, softness_px: float = 0.0) -> TriadMask:
@@ -415,6 +484,7 @@ def apply_crt_effect(
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
     eng = _engine(fr.device, h, w, _lib.PIX_F16 if fr.dtype == torch.float16 else _lib.PIX_U8)
+    triad_mask, vignette_mask = _recognise_triad(triad_mask), _recognise_vignette(vignette_mask)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []
@@ -492,6 +562,7 @@ def apply_static_effects(
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
     eng = _engine(fr.device, h, w, _lib.PIX_F16 if fr.dtype == torch.float16 else _lib.PIX_U8)
+    triad_mask, vignette_mask = _recognise_triad(triad_mask), _recognise_vignette(vignette_mask)
     s = Settings(**{k: v for k, v in locals().items() if k in Settings.FIELDS})
     eng.set_params(s)
     hold = []

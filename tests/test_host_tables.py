@@ -131,3 +131,29 @@ def test_glitch_offsets_match_oracle():
             y0, o = a(h, w, ph, amp, frac)
             y1, e = b(h, w, ph, amp, frac)
             assert y0 == y1 and ((o is None and e is None) or np.array_equal(o, e))
+
+
+def test_reference_built_masks_are_recognised():
+    """effects._recognise_*: plain arrays with the structure of the reference's builders become descriptors (verified
+    element for element, remembered per array object); anything else, and an array rebuilt in place, is looked at again."""
+    from pythoncrt_amd import effects
+    h, w = 60, 84
+    for strength, soft in ((0.35, 0.5), (0.9, 0.0), (0.2, 1.4)):
+        tm = orc.make_triad_mask(h, w, strength, soft)
+        d = effects._recognise_triad(tm)
+        assert isinstance(d, effects.TriadMask) and np.array_equal(np.asarray(d), tm) and effects._recognise_triad(tm) is d
+    for s in (0.25, 0.35, 0.123456, 1.0, 0.0):
+        vg = orc.make_vignette(h, w, s)
+        v = effects._recognise_vignette(vg)
+        assert isinstance(v, effects.VignetteMask) and np.array_equal(np.asarray(v), vg), s
+    rng = np.random.default_rng(0)
+    tm_x = rng.random((h, w, 3)).astype(np.float32)
+    assert effects._recognise_triad(tm_x) is tm_x and effects._recognise_triad(tm_x.astype(np.float64)) is not None
+    vg_x = orc.make_vignette(h, w, 0.3).copy()
+    vg_x[h // 2, w // 2] = 0.5
+    assert effects._recognise_vignette(vg_x) is vg_x
+    tm = orc.make_triad_mask(h, w, 0.35, 0.5)
+    assert isinstance(effects._recognise_triad(tm), effects.TriadMask)
+    tm[0, 0, 0] = 0.5                                   # rebuilt in place: no longer row-identical
+    assert effects._recognise_triad(tm) is tm
+    assert len(effects._RECOGNISED) <= effects._RECOGNISED_MAX

@@ -841,3 +841,33 @@ def test_grade_table_paths(pc, grade, sigma):
         assert np.abs(got - exp.astype(np.float32)).max() <= 3e-7
     else:
         assert_bit_exact(got, exp)
+
+
+def test_reference_built_mask_arrays_take_the_fast_path(pc):
+    """A caller that rebinds only apply_* hands over the reference's own mask arrays (H x W x 3 float32 with identical
+    rows; H x W float64 = 1 - s * clip(nx^2 + ny^2)).  They are recognised (verified element for element) and use the
+    row / analytic path: same bits as with the descriptors, no per-pixel planes in the parameter block.  A mask that
+    does not have that structure stays a plane."""
+    from pythoncrt_amd import effects
+    h, w = 90, 160
+    frame = make_frame(h, w, seed=130, kind="grad")
+    tm_d, vg_d = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.35)
+    tm_a, vg_a = orc.make_triad_mask(h, w, 0.35, 0.5), orc.make_vignette(h, w, 0.35)      # what the reference's builders return
+    assert isinstance(tm_a, np.ndarray) and tm_a.shape == (h, w, 3) and vg_a.dtype == np.float64
+    a = lambda tm, vg: (frame, 0.6, tm, 2.2, False, 1, 1.2, 0.25, 0.0, 1.5, vg, 2.0, 1.0, False, 1, 0, 0.0)
+    kw = dict(noise_seed=3, frame_index=1, warp_strength=0.15)
+    ref = pc.apply_static_effects(*a(tm_d, vg_d), **kw)
+    got = pc.apply_static_effects(*a(tm_a, vg_a), **kw)
+    assert np.array_equal(got, ref)
+    eng = effects._engine(torch.device("cuda", torch.cuda.current_device()), h, w)
+    assert "triad_row" in eng.keep and "triad_full" not in eng.keep and "nx2" in eng.keep and "vig_full" not in eng.keep
+    assert isinstance(effects._recognise_vignette(vg_a), effects.VignetteMask) and effects._recognise_vignette(vg_a).strength == 0.35
+    # an arbitrary mask is left alone and still works (per-pixel plane path), against the oracle
+    rng = np.random.default_rng(131)
+    tm_x = (0.5 + 0.5 * rng.random((h, w, 3))).astype(np.float32)
+    vg_x = 0.5 + 0.5 * rng.random((h, w))
+    assert effects._recognise_triad(tm_x) is tm_x and effects._recognise_vignette(vg_x) is vg_x
+    plane = rng.standard_normal((h, w), dtype=np.float32)
+    g = pc.apply_static_effects(*a(tm_x, vg_x), noise_plane=plane)
+    o = orc.apply_static_effects(*a(tm_x, vg_x), noise_plane=plane)
+    assert np.array_equal(g, o.astype(np.float32))
