@@ -68,3 +68,26 @@ def test_random_render_matches_oracle(case):
     assert (d != 0).mean() <= max(2e-3, 2.0 / d.size), (case, rs, float((d != 0).mean()))
     if rs.persistence > 0.0:
         assert state is not None and np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6
+
+
+@pytest.mark.parametrize("hw", [(6, 20011), (20011, 6), (3, 32767)])
+def test_extreme_aspect_frames(hw):
+    """Very wide / very tall frames (the ctx accepts up to 32767 per side): strip and segment arithmetic, 32-bit
+    offsets and the warp's short-saturated tap origins against the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w)
+    rs = RenderSettings(fast_bloom=False, bloom_sigma=1.2, pixel_size=1, persistence=0.3, warp_strength=0.15, noise_strength=0.0)
+    frames = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pipe = FramePipeline(dev, h, w, rs, fps=25.0, noise_seed=1)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev))
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma",
+                                          "bloom_strength", "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom",
+                                          "pixel_size", "warp_strength")}
+    exp, _ = orc.process_frames(list(frames), params, 25.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength)
+    d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (hw, int(d.max()), float((d != 0).mean()))
