@@ -173,6 +173,12 @@ int crtfx_blend_quantise(crtfx_ctx* ctx, const float* static_dev, float* state_i
 int crtfx_halo_correct_quantise(crtfx_ctx* ctx, const float* local_dev, const float* carry_in_dev,
                                 double coeff, float* state_out_dev, void* out_pix_dev, void* stream);
 
+/* The same fix-up for the first n frames of a chunk in one launch: frame j (local state at local_base_dev +
+ * j*H*W*3 floats) is re-quantised with coeff = persistence^(first_power + j) into out_base + j*out_stride_bytes.
+ * The caller may stop at the frame where persistence^k drops below float32 resolution (shard.settle_frames). */
+int crtfx_halo_correct_batch(crtfx_ctx* ctx, const float* local_base_dev, const float* carry_in_dev, double persistence,
+                             int first_power, int n, void* out_base, size_t out_stride_bytes, void* stream);
+
 /* A run of n frames back to back (the body of the loop at ref:1037-1131): frame i is read at
  * frames_base + i*frame_stride_bytes and written at out_base + i*out_stride_bytes; `frames` is
  * a HOST array of n per-frame records.  persistence > 0 threads state_inout_dev through the

@@ -74,6 +74,7 @@ SYMBOLS = {
     "crtfx_process_batch": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int,
                                            ctypes.POINTER(CrtfxFrame), _vp, ctypes.c_double, ctypes.c_int, _vp, _vp]),
     "crtfx_noise_plane": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
+    "crtfx_halo_correct_batch": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "crtfx_warp_map": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "crtfx_resize_state": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "crtfx_scanline_plane": (ctypes.c_int, [_vp] + [ctypes.c_double] * 5 + [_vp, _vp]),

@@ -12,6 +12,7 @@
 
 #define CRTFX_MAIN_TU 1   // this TU owns the non-template kernels of crtfx_kernels.hip.h
 #include "crtfx.h"
+#include <cmath>
 #include "crtfx_internal.h"
 
 using namespace crtfx;
@@ -653,6 +654,27 @@ int crtfx_halo_correct_quantise(crtfx_ctx* c, const float* local_dev, const floa
     ProfEv pe(c, 1);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
     CRTFX_LAUNCH(k_commit, grid, dim3(256), 0, (hipStream_t)stream, pe.e0, pe.e1, c->H, c->W, local_dev, carry_in_dev, coeff, ko, 1);
+    HIP_TRY(c, hipGetLastError());
+    return CRTFX_OK;
+}
+
+int crtfx_halo_correct_batch(crtfx_ctx* c, const float* local_base_dev, const float* carry_in_dev, double persistence, int first_power,
+                             int n, void* out_base, size_t out_stride_bytes, void* stream) {
+    if (!c) return CRTFX_E_INVALID;
+    if (int rcdev = check_device(c)) return rcdev;
+    if (!local_base_dev || !carry_in_dev || !out_base || n < 0 || first_power < 1) return fail(c, CRTFX_E_INVALID, "bad halo batch arguments");
+    if (!(persistence > 0.0 && persistence < 1.0)) return fail(c, CRTFX_E_INVALID, "persistence %g outside (0,1)", persistence);
+    const size_t frame_elems = (size_t)c->H * c->W * 3;
+    dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4);
+    for (int done = 0; done < n; done += HALO_MAX_FRAMES) {
+        const int m = n - done < HALO_MAX_FRAMES ? n - done : HALO_MAX_FRAMES;
+        HaloCoeffs K{};
+        for (int j = 0; j < m; ++j) K.c[j] = (float)pow(persistence, (double)(first_power + done + j));      // float32(p ** k), as the single-frame entry
+        ProfEv pe(c, 1, m);
+        CRTFX_LAUNCH(k_halo_batch, grid, dim3(256), 0, (hipStream_t)stream, pe.e0, pe.e1, c->H, c->W,
+                     local_base_dev + (size_t)done * frame_elems, frame_elems, carry_in_dev, K, m,
+                     static_cast<uint8_t*>(out_base) + (size_t)done * out_stride_bytes, out_stride_bytes, c->pix_fmt);
+    }
     HIP_TRY(c, hipGetLastError());
     return CRTFX_OK;
 }

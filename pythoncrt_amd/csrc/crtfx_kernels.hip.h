@@ -1538,4 +1538,35 @@ __global__ __launch_bounds__(256) void k_commit(int H, int W, const float* __res
 }
 #endif  // CRTFX_MAIN_TU
 
+// crtfx_halo_correct_batch — the fix-up pass of a frame-sharded chunk for n frames in one launch:
+// out_j = quantise(clip(local_j + coeff_j * carry)), coeff_j = p^(j+1).  A thread keeps its pixel of the carry in
+// registers and walks the chunk's frames, so the carry is read once instead of once per frame.
+constexpr int HALO_MAX_FRAMES = 64;
+struct HaloCoeffs { float c[HALO_MAX_FRAMES]; };
+#ifdef CRTFX_MAIN_TU
+__global__ __launch_bounds__(256) void k_halo_batch(int H, int W, const float* __restrict__ local_base, size_t frame_elems,
+                                                    const float* __restrict__ carry, HaloCoeffs K, int n, uint8_t* __restrict__ out_base,
+                                                    size_t out_stride_bytes, int pix_fmt) {
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    const int x = min(x0 + lane, W - 1);
+    const uint32_t pix = (uint32_t)y * (uint32_t)W + (uint32_t)x;
+    const F3 c = *reinterpret_cast<const F3*>(carry + pix * 3u);
+    KOut O{};
+    O.pix = pix_fmt;
+    for (int j = 0; j < n; ++j) {
+        const F3 l = *reinterpret_cast<const F3*>(local_base + (size_t)j * frame_elems + pix * 3u);
+        const float cf = K.c[j];
+        const float v0 = clip01(l.x + cf * c.x), v1 = clip01(l.y + cf * c.y), v2 = clip01(l.z + cf * c.z);
+        PackedPix pk;
+        if (pix_fmt == CRTFX_PIX_F16) { pk.lo = quant_f16(v0) | (quant_f16(v1) << 16); pk.hi = quant_f16(v2); }
+        else { pk.lo = quant_u8(v0) | (quant_u8(v1) << 8) | (quant_u8(v2) << 16); pk.hi = 0; }
+        O.out_u8 = out_base + (size_t)j * out_stride_bytes;
+        store_row_pix(O, (size_t)y * W + x0, lane, min(64, W - x0), pk);
+    }
+}
+#endif  // CRTFX_MAIN_TU
+
 }  // namespace crtfx

@@ -226,10 +226,11 @@ class GpuShardEngine:
         return out, state
 
     def correct(self, local, carry, p, out):
+        """out[j] = quantise(clip(local[j] + p^(j+1) * carry)) for the whole chunk in one launch per 64 frames."""
         pipe = self.pipe
-        stream = torch.cuda.current_stream(pipe.device).cuda_stream
+        n = int(local.shape[0])
+        assert local.is_contiguous() and out.is_contiguous() and carry.is_contiguous()
         with torch.cuda.device(pipe.device):
-            for j in range(local.shape[0]):
-                rc = pipe.lib.crtfx_halo_correct_quantise(pipe.engine.ctx, local[j].data_ptr(), carry.data_ptr(), p ** (j + 1),
-                                                          None, out[j].data_ptr(), stream)
-                _lib.check(pipe.lib, pipe.engine.ctx, rc)
+            rc = pipe.lib.crtfx_halo_correct_batch(pipe.engine.ctx, local.data_ptr(), carry.data_ptr(), float(p), 1, n, out.data_ptr(),
+                                                   out.stride(0) * out.element_size(), torch.cuda.current_stream(pipe.device).cuda_stream)
+        _lib.check(pipe.lib, pipe.engine.ctx, rc)

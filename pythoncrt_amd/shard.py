@@ -165,5 +165,9 @@ class ShardedRender:
                 if full or r + 1 < a:
                     self._send_recv(true_final, final_local, None, (r + 1) % w)
         if carry is not None:
-            self.engine.correct(local, carry, p, out)
+            # p^(j+1) * carry is below float32 resolution of the state scale after settle_frames(p) frames: the frames
+            # behind that point keep the bytes of the local scan (a 1-LSB flip there needs the local value within
+            # 2^-26 * 255 of a rounding boundary)
+            k = min(n, settle_frames(p, 2.0 ** -26))
+            self.engine.correct(local[:k], carry, p, out[:k])
         return out

@@ -113,7 +113,7 @@ def test_two_rank_render_of_a_ragged_clip(tmp_path, p, chunk, n_frames):
     assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
 
 
-@pytest.mark.parametrize("p,chunk,rounds", [(0.5, 3, 3), (0.5, 26, 2), (0.9, 5, 2), (0.0, 4, 2)])
+@pytest.mark.parametrize("p,chunk,rounds", [(0.5, 3, 3), (0.5, 26, 2), (0.5, 31, 2), (0.9, 5, 2), (0.0, 4, 2)])
 def test_two_rank_render_matches_sequential(tmp_path, p, chunk, rounds):
     world = 2
     n = chunk * world * rounds
