@@ -62,7 +62,25 @@ def cpu_baseline(rs, h, w, fps, n_frames, seed=1234):
     orc.process_frames(frames, params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
                        rs.vignette_strength, noise_planes=planes)
     dt = time.perf_counter() - t0
-    return n_frames / dt, dt
+    # the reference's own topology (ref:1015-1017, 1044-1131): static effects of the frames on a 2-thread pool (numpy and
+    # the C restatement release the GIL), in-order persistence blend + quantise on the main thread
+    from concurrent.futures import ThreadPoolExecutor
+    triad = orc.make_triad_mask(h, w, rs.triad_strength, rs.triad_softness) if rs.triad_strength > 0.0 else None
+    vig = orc.make_vignette(h, w, rs.vignette_strength) if rs.vignette_strength > 0.0 else None
+
+    def static(i):
+        return orc.apply_static_effects(frames[i], params["scanline_strength"], triad, float(params["triad_gamma"]), bool(params["triad_preserve_luma"]),
+                                        params["aberration_px"], params["bloom_sigma"], params["bloom_strength"], float(params["bloom_threshold"]),
+                                        params["noise_strength"], vig, params["scanline_period_px"], (i / float(fps)) * rs.scanline_speed_px_s,
+                                        params["fast_bloom"], params["pixel_size"], 0, 0.0, time_sec=i / float(fps),
+                                        warp_strength=float(params["warp_strength"]), noise_plane=None if planes is None else planes[i])
+    t0 = time.perf_counter()
+    prev = None
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        for st in ex.map(static, range(n_frames)):
+            prev, _ = orc.persistence_blend(prev, st, rs.persistence)
+    dt2 = time.perf_counter() - t0
+    return n_frames / dt, dt, n_frames / dt2
 
 
 def copy_ceiling(device):
@@ -203,10 +221,12 @@ def main():
             }
         if world == 1 and a.cpu_frames != 0 and a.config != 5:
             n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work
-            v, secs = cpu_baseline(rs, h, w, fps, n_cpu)
+            v, secs, v2 = cpu_baseline(rs, h, w, fps, n_cpu)
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{n_cpu} frames of the same {w}x{h} workload through oracle/ (numpy + C restatement of the OpenCV ops), "
-                                             f"{secs:.1f} s on 1 of {os.cpu_count()} host cores"}
+                                             f"{secs:.1f} s on 1 of {os.cpu_count()} host cores",
+                                   "reference_topology": {"workers": 2, "value": round(v2, 4),
+                                                          "note": "the same sample on the reference's 2-thread pool + in-order blend (ref:1015-1017)"}}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
