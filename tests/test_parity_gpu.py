@@ -871,3 +871,22 @@ def test_reference_built_mask_arrays_take_the_fast_path(pc):
     g = pc.apply_static_effects(*a(tm_x, vg_x), noise_plane=plane)
     o = orc.apply_static_effects(*a(tm_x, vg_x), noise_plane=plane)
     assert np.array_equal(g, o.astype(np.float32))
+
+
+def test_baseline_config_1_720p(pc):
+    """BASELINE configs[0]: 1280 x 720, everything off except scanlines 0.6 / period 2 / speed 30 at 30 fps (phase = i):
+    the reference's CPU-runnable case.  Scanline rows come from the reference's numpy expression, so the frames are
+    the oracle's bit for bit."""
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs, h, w = baseline_config(1)
+    assert (h, w) == (720, 1280)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    frames = torch.randint(0, 256, (5, h, w, 3), dtype=torch.uint8, generator=g)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=0)
+    out, _ = pipe.run(frames.to(dev), first_index=0)
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma",
+                                          "bloom_strength", "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size")}
+    exp, _ = orc.process_frames(list(frames.numpy()), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
+                                rs.triad_softness, rs.vignette_strength)
+    assert np.array_equal(out.cpu().numpy(), np.stack(exp))
