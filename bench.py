@@ -211,6 +211,11 @@ def main():
                 "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_launch": int(alg_launch),
                 "algorithmic_bytes_per_frame": alg_bytes_frame, "chain_ms_per_launch_group": round(group_ms, 4),
                 "dominant_kernel": dom,
+                # the same algorithmic bytes over the dominant kernel's launch duration ALONE (the literal per-kernel reading;
+                # `achieved` above also charges the other kernel of the chain and is the smaller, conservative figure)
+                "dominant_kernel_only": {"avg_launch_ms": round(kt[dom][0], 4),
+                                         "achieved": round(alg_launch / (kt[dom][0] * 1e-3) / 1e9, 1),
+                                         "frac": round(alg_launch / (kt[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 # SURVEY 8d's second figure: fabric bytes the PMC passes counted (FETCH_SIZE + WRITE_SIZE, L2 <-> Infinity
                 # Cache/HBM) over the same kernel time, next to what a plain device copy reaches on this box
                 "hbm_achieved": round(traffic / (group_ms * 1e-3) / 1e9, 1) if traffic else None,
