@@ -1086,7 +1086,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     auto phase_c2 = [&](int hbp, const float* ht) {
         const int x = x0 + lane;
         const bool xin = x < W;
-#pragma unroll 1
+        // both rows of the wave unrolled into one block: their LDS / LUT chains interleave (the kernel is latency-bound, not
+        // issue-bound: 4K 164 -> 155 us per 2-frame launch at 127 VGPRs; as a rolled loop it was 115 VGPRs)
+#pragma unroll
         for (int j = wave; j < NB; j += 4) {                  // wave w handles rows w and w + 4
             const int y = hbp - R + j;
             if (y >= y_begin && y < y_end) {                  // wave-uniform
