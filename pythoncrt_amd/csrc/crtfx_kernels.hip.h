@@ -462,7 +462,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
     PackedPix packed{0, 0};
     if (promotes(P)) {
         double v0 = 0, v1 = 0, v2 = 0;
-        if (live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (LEAN || live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);   // lean callers pass valid (replicated) pixels in dead lanes: no branch
         if (O.pre) {
             if (live) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
             return;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
         if (live) packed = commit_pixel<double, COMMIT>(O, pix, v0, v1, v2);
     } else {
         float v0 = 0, v1 = 0, v2 = 0;
-        if (live) tail_masks<float, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
+        if (LEAN || live) tail_masks<float, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);
         if (O.pre) {
             if (live) { float* p = O.pre + pix * 3u; p[0] = v0; p[1] = v1; p[2] = v2; }
             return;
@@ -1019,9 +1019,12 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     // that the loads issued inside the loop depend on no other vector-memory load: a dependent
     // index load in fetch would put an s_waitcnt vmcnt(0) in front of every item's byte loads.
     uint32_t offr[A_ITEMS], offg[A_ITEMS], offb[A_ITEMS];     // element offsets of this item's R, G, B inside a frame row
+    // Items past the end of the NB x SWP tile (the last round is partial) redo the tile's last item: same loads, same
+    // values, same LDS addresses — so the A phase and its prefetch need no per-item branch and stay one basic block.
+#define A_ITEM(u) min(tid + (u) * RR_THREADS, NB * SWP - 1)
 #pragma unroll
     for (int u = 0; u < A_ITEMS; ++u) {
-        const int it = tid + u * RR_THREADS;
+        const int it = A_ITEM(u);
         const int i = it - (it / SWP) * SWP;
         int x = min(max(x0 - pad + i, 0), W - 1);
         if (pixelate) x = P.xmap[x];
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     uint32_t ovx[A_ITEMS], ovpx[A_ITEMS];
 #pragma unroll
     for (int u = 0; u < A_ITEMS; ++u) {
-        const int it = tid + u * RR_THREADS;
+        const int it = A_ITEM(u);
         ovx[u] = (uint32_t)min(max(x0 - pad + (it - (it / SWP) * SWP), 0), W - 1);
         ovpx[u] = 0u;
     }
@@ -1067,10 +1070,10 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         }
 #pragma unroll
         for (int u = 0; u < A_ITEMS; ++u) {
-            const int it = tid + u * RR_THREADS;
+            const int it = A_ITEM(u);
             const int j = it / SWP;
-            if (j < nrows) {
-                const int y = pixelate ? ytab[hb + j - (y_begin - R)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
+            {   // rows past the end of a short last block (j >= nrows) are fetched too: clamped to the frame, never consumed
+                const int y = pixelate ? ytab[min(hb + j - (y_begin - R), y_end - y_begin + 2 * R - 1)] : min(max(hb + j, 0), H - 1);   // BORDER_REPLICATE
                 const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_bytes);   // y, row_bytes < 2^24 and the product < 2^32 for any frame the ctx accepts (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate)
                 raw[u] = load_raw(PIX, F.in, ro + offr[u], ro + offg[u], ro + offb[u]);
                 if (ovl_before)
@@ -1094,7 +1097,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             if (y >= y_begin && y < y_end) {                  // wave-uniform
                 float r = 0, g = 0, b = 0;
                 PixMasks M{cm0, cm1, cm2, 1.0f, 1.0, 0.0f, 0};
-                if (xin) {
+                {   // lanes past the right edge hold the replicated edge pixel (A parks all 64 centre columns): they run the
+                    // same arithmetic and only their stores are masked, so the two rows of the wave stay branch-free
                     int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
                     cr = cr >= CR ? cr - CR : cr;
                     uint32_t s0 = 0, s1 = 0, s2 = 0;
@@ -1168,9 +1172,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         }
 #pragma unroll
         for (int u = 0; u < A_ITEMS; ++u) {
-            const int it = tid + u * RR_THREADS;
+            const int it = A_ITEM(u);
             const int j = it / SWP, i = it - j * SWP;
-            if (j < nrows) {
+            {   // no per-item branch: rows >= nrows of a short last block are graded too and never read
                 float r, g, b;
                 if (use_glut) { r = glut[raw[u].r]; g = glut[256 + raw[u].g]; b = glut[512 + raw[u].b]; }
                 else { r = norm_px(PIX, raw[u].r); g = norm_px(PIX, raw[u].g); b = norm_px(PIX, raw[u].b); grade(P, r, g, b); }
