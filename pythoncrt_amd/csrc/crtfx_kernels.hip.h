@@ -1202,7 +1202,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         for (int u = 0; u < B_ITEMS; ++u) {
             const int it = tid + u * RR_THREADS;
             const int j = it / 48, rem = it - j * 48;
-            if (j < nrows) {
+            // rows >= nrows of a short last block are filtered too (stale staging rows in, never read out): the only
+            // branch left is the wave-uniform one that ends the partial last round (NB * 48 items over RR_THREADS)
+            if (it < NB * 48) {
                 const int c = rem >> 4, gq = rem & 15;
                 // volatile: keeps each 16-byte read whole (ds_read_b128); a plain float4 load is scalarised and
                 // re-merged into ds_read2_b32 pairs
