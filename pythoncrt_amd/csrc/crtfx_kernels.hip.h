@@ -1086,45 +1086,49 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     int crow0 = 0;                 // (hb - (y_begin - R)) % CR
     int c2row0 = NB;               // (hb - NB - y_begin) % CR = CR - R - NB at the first iteration: image row of output row hb - NB - R
     // C2 of the block whose first H-row is hbp: output rows [hbp - R, hbp - R + NB) from tile `ht`
+    // the per-pixel inputs of C2 for row j of the block (output row y): parked centre pixel + bloom, masks of the pixel.
+    // Lanes past the right edge hold the replicated edge pixel (A parks all 64 centre columns): they run the same
+    // arithmetic and only their stores are masked, so there is no branch in here.
+    auto c2_inputs = [&](int j, int y, const float* ht, PixMasks& M, float& r, float& g, float& b) {
+        int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
+        cr = cr >= CR ? cr - CR : cr;
+        uint32_t s0 = 0, s1 = 0, s2 = 0;
+        if constexpr (RTB) { const float* cp = cringf + cr * 3 * TW + lane; r = cp[0]; g = cp[TW]; b = cp[2 * TW]; }
+        else if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
+        else { const uint32_t pk = cring[cr * TW + lane]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
+        const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 5;
+        M.sl = plane_scan ? (j >= 4 ? sp_c2[1] : sp_c2[0]) : __uint_as_float(rt[0]);
+        if (coarse_grain) {        // ref:637-642: horizontal lerp of the two coarse rows, then the vertical one
+            const int sx = cgxo, sy = (int)rt[3];
+            const int sx1 = min(sx + 1, P.gw - 1), sy1 = min(sy + 1, P.gh - 1);
+            const float a1 = cgxa, a0 = 1.0f - a1, b1 = __uint_as_float(rt[4]), b0 = 1.0f - b1;
+            const float n00 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx), n01 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx1);
+            const float n10 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx), n11 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx1);
+            M.z = (n00 * a0 + n01 * a1) * b0 + (n10 * a0 + n11 * a1) * b1;
+            M.has_z = 1;
+        }
+        if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
+        if constexpr (!RTB) {
+            r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
+            grade(P, r, g, b);
+        }
+        r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
+        g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
+        b = clip01(b + P.bloom_strength * ht[(j * 3 + 2) * TW + lane]);
+    };
+    // C2 of the block whose first H-row is hbp: output rows [hbp - R, hbp - R + NB) from tile `ht`; wave w handles rows
+    // w and w + 4, unrolled: the kernel is latency-bound rather than issue-bound and the LDS / LUT chains of the two rows
+    // interleave (4K 164 -> 155 us per 2-frame launch; merging them into one straight-line block by hand adds nothing).
     auto phase_c2 = [&](int hbp, const float* ht) {
         const int x = x0 + lane;
         const bool xin = x < W;
-        // both rows of the wave unrolled into one block: their LDS / LUT chains interleave (the kernel is latency-bound, not
-        // issue-bound: 4K 164 -> 155 us per 2-frame launch at 127 VGPRs; as a rolled loop it was 115 VGPRs)
 #pragma unroll
-        for (int j = wave; j < NB; j += 4) {                  // wave w handles rows w and w + 4
+        for (int j = wave; j < NB; j += 4) {
             const int y = hbp - R + j;
             if (y >= y_begin && y < y_end) {                  // wave-uniform
                 float r = 0, g = 0, b = 0;
                 PixMasks M{cm0, cm1, cm2, 1.0f, 1.0, 0.0f, 0};
-                {   // lanes past the right edge hold the replicated edge pixel (A parks all 64 centre columns): they run the
-                    // same arithmetic and only their stores are masked, so the two rows of the wave stay branch-free
-                    int cr = c2row0 + j;                       // (y - (y_begin - R)) % CR without the division
-                    cr = cr >= CR ? cr - CR : cr;
-                    uint32_t s0 = 0, s1 = 0, s2 = 0;
-                    if constexpr (RTB) { const float* cp = cringf + cr * 3 * TW + lane; r = cp[0]; g = cp[TW]; b = cp[2 * TW]; }
-                    else if constexpr (PIX) { const uint16_t* cp = cring16 + cr * 3 * TW + lane; s0 = cp[0]; s1 = cp[TW]; s2 = cp[2 * TW]; }
-                    else { const uint32_t pk = cring[cr * TW + lane]; s0 = pk & 255u; s1 = (pk >> 8) & 255u; s2 = (pk >> 16) & 255u; }
-                    const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 5;
-                    M.sl = plane_scan ? (j >= 4 ? sp_c2[1] : sp_c2[0]) : __uint_as_float(rt[0]);
-                    if (coarse_grain) {        // ref:637-642: horizontal lerp of the two coarse rows, then the vertical one
-                        const int sx = cgxo, sy = (int)rt[3];
-                        const int sx1 = min(sx + 1, P.gw - 1), sy1 = min(sy + 1, P.gh - 1);
-                        const float a1 = cgxa, a0 = 1.0f - a1, b1 = __uint_as_float(rt[4]), b0 = 1.0f - b1;
-                        const float n00 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx), n01 = grain_normal(F.key0, F.key1, (uint32_t)sy * P.gw + sx1);
-                        const float n10 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx), n11 = grain_normal(F.key0, F.key1, (uint32_t)sy1 * P.gw + sx1);
-                        M.z = (n00 * a0 + n01 * a1) * b0 + (n10 * a0 + n11 * a1) * b1;
-                        M.has_z = 1;
-                    }
-                    if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
-                    if constexpr (!RTB) {
-                        r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
-                        grade(P, r, g, b);
-                    }
-                    r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
-                    g = clip01(g + P.bloom_strength * ht[(j * 3 + 1) * TW + lane]);
-                    b = clip01(b + P.bloom_strength * ht[(j * 3 + 2) * TW + lane]);
-                }
+                c2_inputs(j, y, ht, M, r, g, b);
                 emit_pixel<true, RTB>(P, F, O, y, x0, lane, xin, M, r, g, b, lut, lut + LUT_STRIDE);
             }
         }
