@@ -382,7 +382,10 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         const bool lean = !c->force_generic && !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full &&
                           !c->kp.vig_full && !kf.scan_plane && !kf.noise_plane && !kf.overlay_before && c->kp.grain <= 1 &&
                           !k1.overlay_after && !k1.out_f32 && (k1.blend == CRTFX_BLEND_NONE || k1.blend == CRTFX_BLEND_RENDER);
-        if (lean) launch_point_lean(c, gates == SF_FAST_PIX, k1.blend == CRTFX_BLEND_RENDER, grid, dim3(64 * waves), s, pe.e0, pe.e1, kf, k1);
+        if (lean) {
+            dim3 glean(grid.x, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
+            launch_point_lean(c, gates == SF_FAST_PIX, k1.blend == CRTFX_BLEND_RENDER, glean, dim3(64 * waves), s, pe.e0, pe.e1, kf, k1);
+        }
         else if (!c->force_generic && !((fl & CRTFX_F_NOISE) && c->kp.grain > 1)) {      // any gate set, loads branch-free
             if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_F16>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
             else { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_U8>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }

@@ -679,9 +679,13 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
 // basic block: the index-table loads, then the byte / half-res / mask / state loads issue together instead of one
 // memory round trip per stage (the general k_point waits at every branch that contains a load: ~5 dependent round
 // trips per wavefront made the 1080p reference-CLI-default chain latency-bound at 33 us).
+#ifndef CRTFX_POINT_ROWS
+#define CRTFX_POINT_ROWS 2      // output rows per k_point_lean thread (rows y, y + waves): their load chains interleave
+#endif
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KOut Oin) {
     __shared__ float lut[2 * LUT_STRIDE];
+    constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
     P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
     KFrame F = Fin;
@@ -694,35 +698,58 @@ __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KO
     }
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
-    const int y = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (y >= P.H) return;
+    const int waves = blockDim.x >> 6;
+    const int ybase = blockIdx.y * (waves * ROWS) + (threadIdx.x >> 6);
+    if (ybase >= P.H) return;
     const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
-    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-    const PixMasks M = load_masks(P, F, y, x);
-    float r, g, b;
-    fetch_graded(P, F, y, x, r, g, b);
-    if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
-        const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
-        const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
-        const float a1 = P.ux_a[x], a0 = 1.0f - a1, b1 = P.uy_a[y], b0 = 1.0f - b1;
-        const F3 p00 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx) * 3);
-        const F3 p01 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx1) * 3);
-        const F3 p10 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx) * 3);
-        const F3 p11 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx1) * 3);
-        const float bl0 = (p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1;
-        const float bl1 = (p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1;
-        const float bl2 = (p00.z * a0 + p01.z * a1) * b0 + (p10.z * a0 + p11.z * a1) * b1;
-        r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
-    }
     using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
-    T v0, v1, v2;
-    tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v0, v1, v2);
-    if (O.pre) {                                 // two-kernel path: park the pre-warp pixel for k_warp
-        *reinterpret_cast<F3*>(O.pre + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
+    T v[ROWS][3];
+    int yr[ROWS];
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int y = yr[k] = min(ybase + k * waves, P.H - 1);     // a row past the bottom redoes the last one; its stores are skipped
+        const PixMasks M = load_masks(P, F, y, x);
+        float r, g, b;
+        fetch_graded(P, F, y, x, r, g, b);
+        if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
+            const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
+            const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
+            const float a1 = P.ux_a[x], a0 = 1.0f - a1, b1 = P.uy_a[y], b0 = 1.0f - b1;
+            const F3 p00 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx) * 3);
+            const F3 p01 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy * P.hw + sx1) * 3);
+            const F3 p10 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx) * 3);
+            const F3 p11 = *reinterpret_cast<const F3*>(P.ds + ((size_t)sy1 * P.hw + sx1) * 3);
+            const float bl0 = (p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1;
+            const float bl1 = (p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1;
+            const float bl2 = (p00.z * a0 + p01.z * a1) * b0 + (p10.z * a0 + p11.z * a1) * b1;
+            r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+        }
+        tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
+    }
+    if (O.pre) {                                 // two-kernel path: park the pre-warp pixels for k_warp
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            if (ybase + k * waves < P.H)
+                *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
         return;
     }
-    const PackedPix pk = commit_pixel<T, true>(O, pix, v0, v1, v2);
-    if (O.out_u8) store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), pk);
+    if (ybase + (ROWS - 1) * waves < P.H) {      // every row of this wave is inside the frame (wave-uniform): one block for all commits
+        PackedPix pk[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            pk[k] = commit_pixel<T, true>(O, (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x, v[k][0], v[k][1], v[k][2]);
+        if (O.out_u8) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk[k]);
+        }
+    } else {                                     // bottom edge: only the rows that exist are committed (the state must be blended once)
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            if (ybase + k * waves < P.H) {
+                const PackedPix pk = commit_pixel<T, true>(O, (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x, v[k][0], v[k][1], v[k][2]);
+                if (O.out_u8) store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+            }
+    }
 }
 #endif  // CRTFX_MAIN_TU
 
