@@ -934,8 +934,10 @@ __host__ __device__ constexpr int rr_cring(int R) { return R + 2 * NB; }   // ex
 __host__ __device__ constexpr int rr_cring_floats(int R, int pix, bool runtime) {
     return runtime ? rr_cring(R) * TW * 3 : (pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW);
 }
+// The gate-folded uint8 build also keeps u / 255.0 for the 256 sample codes in LDS (1 KB): a table read replaces the
+// convert + corrected-reciprocal arithmetic of a1 in the A phase and again for the parked centre pixel in C2.
 __host__ __device__ constexpr int rr_lds_fixed_floats(int R, int pix, bool runtime = false) {
-    return NB * 3 * rr_sws(R, pix || runtime) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring_floats(R, pix, runtime);
+    return NB * 3 * rr_sws(R, pix || runtime) + 2 * NB * 3 * TW + 2 * LUT_STRIDE + rr_cring_floats(R, pix, runtime) + ((!pix && !runtime) ? 256 : 0);
 }
 
 // SF: the stage gates (crtfx_params.flags without CRTFX_F_WARP, which k_phosphor never reads) as a
@@ -986,6 +988,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     float* cringf = reinterpret_cast<float*>(cring);                        // runtime-gate build: [CR][3][TW] graded floats
     uint32_t* rowtab = cring + rr_cring_floats(R, PIX, SF == 0xFFFFFFFFu);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
     int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);
+    constexpr bool NLUT = (SF != 0xFFFFFFFFu) && PIX == 0;                 // gate-folded uint8 build: a1 from a 256-entry LDS table
+    float* nlut = reinterpret_cast<float*>(ytab);                          // (that build never pixelates: ytab is empty)
     float* glut = reinterpret_cast<float*>(ytab + ((Pin.flags & CRTFX_F_PIXELATE) ? seg_rows + 2 * R : 0));   // [3][256] grade table (runtime-gate build)                   // [seg_rows + 2R]: source row of halo row (pixelate)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
@@ -1063,6 +1067,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     // The overlay pixel of a staged halo position is the one at its clamped (BORDER_REPLICATE) frame position — the
     // pixelate maps do not apply to it (a3 comes before the overlay).
     const bool ovl_before = RTB && F.overlay_before != nullptr;
+    if constexpr (NLUT) { if (tid < 256) nlut[tid] = norm_u8((uint32_t)tid); }      // the same values norm_u8 computes, by construction
     const bool use_glut = RTB && PIX == 0 && P.grade_lut != nullptr;
     if (use_glut)
         for (int i = tid; i < 768; i += RR_THREADS) glut[i] = P.grade_lut[i];
@@ -1136,7 +1141,8 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         }
         if (fl & CRTFX_F_VIGNETTE) M.vig = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
         if constexpr (!RTB) {
-            r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2);
+            if constexpr (NLUT) { r = nlut[s0]; g = nlut[s1]; b = nlut[s2]; }
+            else { r = norm_px(PIX, s0); g = norm_px(PIX, s1); b = norm_px(PIX, s2); }
             grade(P, r, g, b);
         }
         r = clip01(r + P.bloom_strength * ht[(j * 3 + 0) * TW + lane]);   // ref:611
@@ -1208,6 +1214,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
             {   // no per-item branch: rows >= nrows of a short last block are graded too and never read
                 float r, g, b;
                 if (use_glut) { r = glut[raw[u].r]; g = glut[256 + raw[u].g]; b = glut[512 + raw[u].b]; }
+                else if constexpr (NLUT) { r = nlut[raw[u].r]; g = nlut[raw[u].g]; b = nlut[raw[u].b]; grade(P, r, g, b); }
                 else { r = norm_px(PIX, raw[u].r); g = norm_px(PIX, raw[u].g); b = norm_px(PIX, raw[u].b); grade(P, r, g, b); }
                 if (ovl_before) overlay_blend_px<float>(ovpx[u], r, g, b);
                 if (i >= pad && i < pad + TW) {     // centre column: park the pixel for C2 (graded floats, or the packed samples)
