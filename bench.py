@@ -99,24 +99,82 @@ def copy_ceiling(device):
     return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def main():
+def source_hash():
+    """Fingerprint of the device code a PMC measurement belongs to (profiles/traffic.json carries the same field):
+    sha1 over the kernel sources, so that a stale traffic figure is never attached to a different build."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("pythoncrt_amd/csrc/crtfx_kernels.hip.h", "pythoncrt_amd/csrc/crtfx.hip", "pythoncrt_amd/csrc/crtfx_rr.hip",
+              "pythoncrt_amd/csrc/crtfx_internal.h", "include/crtfx.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[N-1]; 0 = the reference CLI's default flags at 1080p")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default 16 at 4K, 32 at 1080p)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 256 at 4K, 512 at 1080p, 48 at 8K — sized so that 20 steps run >= 0.5 s)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    a = ap.parse_args()
+    ap.add_argument("--repeats", type=int, default=2, help="further timed regions of K steps after the reported one (spread only; 0 = none)")
+    ap.add_argument("--tables-outside", action="store_true", help="build the per-frame host tables before the timed region (A/B of the host share)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py launches the ranks itself")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="libcrtfx testing/tuning switch (crtfx_set_option), e.g. NO_CC=1; never part of a reported result")
+    return ap.parse_args(argv)
 
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
+    (python -m torch.distributed.run ... bench.py <same flags>) and relay rank 0's JSON line.  This parent never
+    touches the GPU (no torch.cuda / HIP call), so nothing that has initialised a device is ever replaced or forked."""
+    import socket
+    import subprocess
+    port = a.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [x for x in sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+    print(line)
+    raise SystemExit(0)
+
+
+def main():
+    a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                      # never returns
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl")      # "gloo": rehearsal of several ranks on fewer GPUs (never a result)
@@ -128,25 +186,50 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
+    from pythoncrt_amd import effects
     from pythoncrt_amd.pipeline import FramePipeline, GpuShardEngine, baseline_config
-    from pythoncrt_amd.shard import FrameShard, ShardedRender
+    from pythoncrt_amd.shard import FrameShard, ShardedRender, settle_frames
+    for o in a.opt:
+        k, v = o.split("=", 1)
+        effects.DEBUG_OPTIONS[k.strip().upper()] = int(v)
     rs, h, w = baseline_config(a.config)
     fps = 30.0
-    B = a.batch or (4 if h >= 4320 else 16 if h >= 2160 else 32)
+    p = rs.persistence
+    # frames per step: enough that the default 20 steps run >= 0.5 s (4K: 256 frames = 6.4 GB in + 6.4 GB out of the
+    # 288 GB; the sharded-persistence config needs B >= settle_frames(p) anyway, see shard.py)
+    from pythoncrt_amd.shard import choose_chunk
+    B = a.batch or (48 if h >= 4320 else 256 if h >= 2160 else 512)
+    if p > 0.0 and not a.batch:
+        # sharded persistence: a chunk covers the IIR's settling time, so every round is ONE parallel hop (shard.py)
+        B = choose_chunk(p, h * w * 12, 128)
     dtype = torch.float16 if a.config == 5 else torch.uint8
     pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234, dtype=dtype)
     frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank).to(dtype)
-    p = rs.persistence
     shard = FrameShard(world, rank, B)
-    engine = GpuShardEngine(pipe, B)
-    render = ShardedRender(shard, p, engine, dist=dist)
+    sharded_iir = p > 0.0 and world > 1
+    engine = GpuShardEngine(pipe, B, slots=2 if sharded_iir else 1)
+    render = ShardedRender(shard, p, engine, dist=dist, overlap=sharded_iir, timing=sharded_iir)
 
-    # step s = round s of the frame-sharded render: rank r owns global frames [(s*world + r)*B, ... + B)
-    for s_ in range(a.warmup + a.steps):     # host-side per-frame tables are built outside the timed region
+    # step s = round s of the frame-sharded render: rank r owns global frames [(s*world + r)*B, ... + B).
+    # The per-frame host tables of a step (scanline row gains via np.sin, flicker factors, the ctypes frame records and
+    # their upload) are built INSIDE the timed region, as a render has to; the GPU works on step s meanwhile.
+    n_regions = 1 + max(0, a.repeats)
+    total_steps = a.warmup + a.steps * n_regions
+    host_s = [0.0]
+
+    def build_tables(s_):
+        t = time.perf_counter()
         engine.records[(s_ * world + rank) * B] = pipe.frame_records((s_ * world + rank) * B, B)
+        host_s[0] += time.perf_counter() - t
+
+    if a.tables_outside:
+        for s_ in range(total_steps):
+            build_tables(s_)
 
     def one_step(s_):
-        render.run_round(frames, s_)
+        if not a.tables_outside:
+            build_tables(s_)
+        render.submit_round(frames, s_)        # overlapped schedule when the IIR is sharded (results one call late), else run_round
 
     def sync():
         torch.cuda.synchronize(device)
@@ -156,20 +239,39 @@ def main():
 
     for s in range(a.warmup):
         one_step(s)
+    render.flush()
     sync()
     prof = not a.no_profile
-    pipe.profile(4 if prof else 0)      # HIP events on the launches of every 4th frame of the timed region
-    t0 = time.perf_counter()
-    for s in range(a.warmup, a.warmup + a.steps):
-        one_step(s)
-    sync()
-    dt = time.perf_counter() - t0
-    kt = pipe.profile_read() if prof else {}
-    pipe.profile(False)
+    region_dt = []
+    kt = {}
+    for reg in range(n_regions):
+        first = a.warmup + reg * a.steps
+        host_s[0] = 0.0
+        if reg == 0:
+            pipe.profile(8 if prof else 0)      # HIP events on the launches of every 8th frame of the reported region
+        t0 = time.perf_counter()
+        for s in range(first, first + a.steps):
+            one_step(s)
+        render.flush()
+        sync()
+        dt_r = time.perf_counter() - t0
+        if reg == 0:
+            kt = pipe.profile_read() if prof else {}
+            pipe.profile(False)
+            host_first = host_s[0]
+        if dist is not None:
+            t = torch.tensor([dt_r], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        region_dt.append(dt_r)
+    dt = region_dt[0]
+
+    per_rank = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([B * a.steps / dt], dtype=torch.float64, device=device)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [round(float(v.item()), 2) for v in allv]
 
     total_frames = B * a.steps * world
     fps_out = total_frames / dt
@@ -183,7 +285,16 @@ def main():
         "config": {"workload": (f"BASELINE configs[{a.config - 1}]" if a.config else "reference CLI defaults (fast bloom, pixel_size 2)") + f": {w}x{h} chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
                                f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, {'fp16' if a.config == 5 else 'u8'} in/out",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
+        "timed_region_s": round(dt, 4),
+        **({"tuning_options": dict(effects.DEBUG_OPTIONS)} if effects.DEBUG_OPTIONS else {}),
+        "host_tables": {"in_timed_region": not a.tables_outside, "host_seconds_rank0": round(host_first, 4),
+                        "note": "per-frame scanline/flicker tables + frame records built and uploaded per step; they overlap the previous step's kernels"},
+        "repeat_values": [round(total_frames / d, 2) for d in region_dt[1:]],
+        "dist": {"backend": backend if world > 1 else None, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
+                 "per_rank_frames_per_s": per_rank},
     }
+    if p > 0.0 and world > 1:
+        res["shard_schedule"] = render.schedule_report()
     if rank == 0:
         if kt:
             # kt[k] = (mean ms per launch, timed launches, frames they covered): a launch of the dominant kernel
@@ -196,17 +307,41 @@ def main():
             group_ms = sum(per_frame_ms.values()) * fpl
             alg_launch = alg_bytes_frame * fpl
             achieved = alg_launch / (group_ms * 1e-3) / 1e9
-            traffic = None
+            # PMC traffic: only when profiles/traffic.json was measured on THIS device code and this config
+            traffic = traffic_raw = None
+            tsrc = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    t_frame = json.load(open(tpath)).get(f"config{a.config}")        # PMC bytes per frame (tools/summarise_profiles.py)
-                    traffic = int(t_frame * fpl) if t_frame else None
+                    tj = json.load(open(tpath))
+                    ent = tj.get(f"config{a.config}")
+                    if isinstance(ent, dict) and ent.get("source_hash") == source_hash():
+                        traffic = int(ent["bytes_per_frame_corrected"] * fpl)
+                        traffic_raw = int(ent["bytes_per_frame_as_reported"] * fpl)
+                        tsrc = {k: ent.get(k) for k in ("source_hash", "tag", "batch", "correction")}
+                    elif isinstance(ent, dict):
+                        tsrc = {"stale": True, "measured_on": ent.get("source_hash"), "this_build": source_hash()}
                 except Exception:
                     traffic = None
+            valu = None
+            vpath = os.path.join(ROOT, "profiles", "valu.json")
+            if os.path.exists(vpath):
+                try:
+                    vj = json.load(open(vpath)).get(f"config{a.config}")
+                    if isinstance(vj, dict) and vj.get("source_hash") == source_hash():
+                        wi = vj["valu_wave_insts_per_frame"]
+                        # issue slots of the chip over the chain's kernel time: 1024 SIMDs, one wave-instruction per 2 cycles
+                        # (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU op takes 2 cycles), at the clock the run held
+                        clk = vj.get("clock_ghz", 2.4)
+                        slots = 1024 * (group_ms / fpl * 1e-3) * clk * 1e9 / 2.0
+                        valu = {"wave_insts_per_frame": int(wi), "issue_frac": round(wi / slots, 4), "clock_ghz": clk,
+                                "source": {k: vj.get(k) for k in ("source_hash", "tag")}}
+                except Exception:
+                    valu = None
             res["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_as_reported": traffic_raw, "traffic_source": tsrc,
                 "kernel": f"{dom} (+ the other kernel of the chain over the same frames): algorithmic bytes of the frames of one launch / their summed kernel time",
                 "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_launch": int(alg_launch),
                 "algorithmic_bytes_per_frame": alg_bytes_frame, "chain_ms_per_launch_group": round(group_ms, 4),
@@ -220,6 +355,8 @@ def main():
                 # Cache/HBM) over the same kernel time, next to what a plain device copy reaches on this box
                 "hbm_achieved": round(traffic / (group_ms * 1e-3) / 1e9, 1) if traffic else None,
                 "hbm_frac": round(traffic / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                "hbm_frac_as_reported": round(traffic_raw / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_raw else None,
+                "valu": valu,
                 "copy_ceiling": copy_ceiling(device),
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
@@ -228,6 +365,7 @@ def main():
             n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work
             v, secs, v2 = cpu_baseline(rs, h, w, fps, n_cpu)
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
                                    "sample": f"{n_cpu} frames of the same {w}x{h} workload through oracle/ (numpy + C restatement of the OpenCV ops), "
                                              f"{secs:.1f} s on 1 of {os.cpu_count()} host cores",
                                    "reference_topology": {"workers": 2, "value": round(v2, 4),

@@ -143,7 +143,10 @@ typedef struct crtfx_ctx crtfx_ctx;
 
 int crtfx_version(void);
 
-/* ctx owns device-side tables and the H*W*3 float32 pre-warp scratch image. */
+/* ctx owns device-side tables and the H*W*3 float32 pre-warp scratch image.  crtfx_create, crtfx_destroy and
+ * crtfx_set_params do their work on the ctx's device and restore the calling thread's current device before they
+ * return; every other entry point launches on the CURRENT device and refuses (CRTFX_E_INVALID) when that is not the
+ * ctx's. */
 int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out_ctx);
 int crtfx_destroy(crtfx_ctx* ctx);
 const char* crtfx_last_error(const crtfx_ctx* ctx);
@@ -210,6 +213,26 @@ int crtfx_noise_plane(crtfx_ctx* ctx, uint64_t seed, uint64_t frame_index, float
 /* The fixed-point sampling map of the barrel warp (ref:338-347 + cv2.remap's 1/32-px
  * quantisation): integer tap origin and packed (fy<<5|fx) fraction per output pixel. */
 int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fxy_dev, void* stream);
+
+/* Testing / tuning switches of one ctx (the product path never needs them; nothing in the library reads the
+ * environment).  Call crtfx_set_params again afterwards: launch shapes are planned there.
+ *   FORCE_GENERIC        always take the general-purpose kernels (the LDS-ring k_phosphor, k_point, k_warp)
+ *   FORCE_RUNTIME_FLAGS  never take a gate-folded instantiation
+ *   NO_CC                full-chain launches that park a pre-warp image stay on k_phosphor_rr (A/B against k_phosphor_cc)
+ *   GROUP, SEG_ROWS      frames per grid (1..4) / rows per block of the register-window kernels; 0 = the planner's choice
+ *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4)
+ *   POINT_TILES          rows per k_point block (1..16; 0 = default)
+ *   OVERLAP              run k_warp(n) on a side stream beside k_phosphor(n+1) (measured slower; kept for A/B)
+ *   DEBUG_PLAN           print the planned launch shape to stderr */
+typedef enum crtfx_option {
+    CRTFX_OPT_FORCE_GENERIC = 1, CRTFX_OPT_FORCE_RUNTIME_FLAGS = 2, CRTFX_OPT_NO_CC = 3, CRTFX_OPT_GROUP = 4, CRTFX_OPT_SEG_ROWS = 5,
+    CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9
+} crtfx_option;
+int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
+
+/* -DCRTFX_STAMP diagnostic builds only (tools/phase_profile.py): device buffer the per-wave phase cycle sums are
+ * written to.  CRTFX_E_UNSUPPORTED in the product build. */
+int crtfx_debug_buffer(crtfx_ctx* ctx, void* dev_ptr);
 
 /* HIP-event timing of the launches while profiling is on (events attached to the dispatch packets):
  * on = 0 off, 1 every frame, N > 1 every N-th frame (sampling keeps the overhead negligible).

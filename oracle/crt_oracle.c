@@ -68,6 +68,78 @@ int orc_sepblur_f32(const float* src, float* dst, float* tmp, int h, int w, int 
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * ALTERNATIVE ACCUMULATION FORMS of the same separable blur — not the oracle, the SPREAD around it.
+ * cv2.GaussianBlur on CV_32F is "parity unpinned" (no reference-held vector, cv2 not installable here), and OpenCV's
+ * own code paths do not all add the taps in the order orc_sepblur_f32 does.  The forms OpenCV 4.x's C++ filter
+ * engine (modules/imgproc/src/filter.simd.hpp) is known to contain are restated here so that tests can measure how
+ * far each lies from the oracle and hold the GPU frame against EVERY one of them (tests/test_oracle_variants.py,
+ * tests/test_parity_gpu.py::test_gpu_within_every_opencv_variant):
+ *   row_mode 0  RowFilter, taps left to right, fused multiply-add (AVX2/FMA3 dispatch: v_muladd)      = the oracle
+ *            1  RowFilter, taps left to right, multiply then add (SSE baseline)
+ *            2  SymmRowSmallFilter for ksize <= 5 (x0*k0 + (x-1 + x+1)*k1 [+ (x-2 + x+2)*k2]), FMA; else as mode 0
+ *            3  the same without FMA; else as mode 1
+ *   col_mode 0  ColumnFilter, taps top to bottom, FMA                                                  = the oracle
+ *            1  SymmColumnFilter: centre tap first, then (S[+k] + S[-k]) * f[k] outwards, FMA
+ *            2  SymmColumnFilter without FMA
+ *            3  ColumnFilter, taps top to bottom, multiply then add
+ * (The IPP path of the pip wheels, ippiFilterGaussianBorder, is closed arithmetic and cannot be restated.) */
+int orc_sepblur_f32_variant(const float* src, float* dst, float* tmp, int h, int w, int cn,
+                            const float* kx, int nkx, const float* ky, int nky, int row_mode, int col_mode)
+{
+    const int rx = nkx / 2, ry = nky / 2;
+    const int row_small = (row_mode >= 2) && nkx <= 5 && nkx >= 3;
+    const int row_fma = (row_mode == 0 || row_mode == 2);
+    for (int y = 0; y < h; ++y) {
+        const float* srow = src + (size_t)y * w * cn;
+        float* trow = tmp + (size_t)y * w * cn;
+        for (int x = 0; x < w; ++x) {
+            for (int c = 0; c < cn; ++c) {
+                float s;
+#define SX(d) srow[(size_t)clampi(x + (d), 0, w - 1) * cn + c]
+                if (row_small) {
+                    if (row_fma) {
+                        s = SX(0) * kx[rx];
+                        for (int k = 1; k <= rx; ++k) s = fmaf(SX(-k) + SX(k), kx[rx + k], s);
+                    } else {
+                        s = SX(0) * kx[rx];
+                        for (int k = 1; k <= rx; ++k) { const float t = (SX(-k) + SX(k)) * kx[rx + k]; s = s + t; }
+                    }
+                } else if (row_fma) {
+                    s = 0.0f;
+                    for (int k = 0; k < nkx; ++k) s = fmaf(SX(k - rx), kx[k], s);
+                } else {
+                    s = SX(-rx) * kx[0];
+                    for (int k = 1; k < nkx; ++k) { const float t = SX(k - rx) * kx[k]; s = s + t; }
+                }
+#undef SX
+                trow[(size_t)x * cn + c] = s;
+            }
+        }
+    }
+    const size_t rowlen = (size_t)w * cn;
+    for (int y = 0; y < h; ++y) {
+        float* drow = dst + (size_t)y * rowlen;
+#define TR(d) (tmp + (size_t)clampi(y + (d), 0, h - 1) * rowlen)
+        if (col_mode == 0) {
+            for (size_t i = 0; i < rowlen; ++i) drow[i] = 0.0f;
+            for (int k = 0; k < nky; ++k) { const float* t = TR(k - ry); const float f = ky[k]; for (size_t i = 0; i < rowlen; ++i) drow[i] = fmaf(t[i], f, drow[i]); }
+        } else if (col_mode == 3) {
+            { const float* t = TR(-ry); const float f = ky[0]; for (size_t i = 0; i < rowlen; ++i) drow[i] = t[i] * f; }
+            for (int k = 1; k < nky; ++k) { const float* t = TR(k - ry); const float f = ky[k]; for (size_t i = 0; i < rowlen; ++i) { const float p = t[i] * f; drow[i] = drow[i] + p; } }
+        } else {
+            { const float* t = TR(0); const float f = ky[ry]; for (size_t i = 0; i < rowlen; ++i) drow[i] = t[i] * f; }
+            for (int k = 1; k <= ry; ++k) {
+                const float* ta = TR(k); const float* tb = TR(-k); const float f = ky[ry + k];
+                if (col_mode == 1) for (size_t i = 0; i < rowlen; ++i) drow[i] = fmaf(ta[i] + tb[i], f, drow[i]);
+                else for (size_t i = 0; i < rowlen; ++i) { const float p = (ta[i] + tb[i]) * f; drow[i] = drow[i] + p; }
+            }
+        }
+#undef TR
+    }
+    return 0;
+}
+
 /* cvRound for float: round half to even (SSE cvtss2si under the default MXCSR). */
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 
@@ -127,6 +199,29 @@ int orc_remap_bilinear_f64(const double* src, double* dst, int h, int w, int cn,
                            const float* mapx, const float* mapy)
 {
     REMAP_BODY(double, double)
+    return 0;
+}
+
+/* Spread form of the same interpolation: the four products contracted into fused multiply-adds, as a compiler does
+ * with -ffp-contract=fast on a baseline that has FMA (aarch64 wheels; x86-64 wheels build imgwarp.cpp for SSE3 and do
+ * not).  r = fma(v3, w3, fma(v2, w2, fma(v1, w1, v0 * w0))). */
+#undef REMAP_COMBINE
+int orc_remap_bilinear_f64_fma(const double* src, double* dst, int h, int w, int cn, const float* mapx, const float* mapy)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t m = (size_t)y * w + x;
+            int sxq = cv_round_f(mapx[m] * 32.0f), syq = cv_round_f(mapy[m] * 32.0f);
+            int sx = sat_short(sxq >> 5), sy = sat_short(syq >> 5);
+            float fx = (float)(sxq & 31) * (1.0f / 32.0f), fy = (float)(syq & 31) * (1.0f / 32.0f);
+            const double w0 = (1.0f - fy) * (1.0f - fx), w1 = (1.0f - fy) * fx, w2 = fy * (1.0f - fx), w3 = fy * fx;
+            for (int c = 0; c < cn; ++c) {
+#define TAPV(yy, xx) (((xx) >= 0 && (xx) < w && (yy) >= 0 && (yy) < h) ? src[((size_t)(yy) * w + (xx)) * cn + c] : 0.0)
+                const double v0 = TAPV(sy, sx), v1 = TAPV(sy, sx + 1), v2 = TAPV(sy + 1, sx), v3 = TAPV(sy + 1, sx + 1);
+#undef TAPV
+                dst[m * cn + c] = fma(v3, w3, fma(v2, w2, fma(v1, w1, v0 * w0)));
+            }
+        }
     return 0;
 }
 
@@ -267,6 +362,18 @@ int orc_convert_scale_abs_f64(const double* src, uint8_t* dst, size_t n, float a
     return 0;
 }
 
+/* Spread form: the scalar tail of cvtabs_32f for a CV_64F source multiplies in double (src[j] * a with a float a,
+ * no narrowing first): u8 = saturate(cvRound(|x * 255.0|)) with the double rounded to nearest-even by cvRound(double). */
+int orc_convert_scale_abs_f64_dbl(const double* src, uint8_t* dst, size_t n, float alpha)
+{
+    for (size_t i = 0; i < n; ++i) {
+        double v = fabs(src[i] * (double)alpha);
+        long r = lrint(v);
+        dst[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    return 0;
+}
+
 /* cv2.addWeighted(a, alpha, b, beta, 0): dst = fma(a, alpha, fma(b, beta, gamma)) in the
  * array's own type (scalars narrowed to float for CV_32F). crt_filter.py:693. */
 int orc_add_weighted_f32(const float* a, float alpha, const float* b, float beta, float* dst, size_t n)
@@ -281,4 +388,4 @@ int orc_add_weighted_f64(const double* a, double alpha, const double* b, double 
     return 0;
 }
 
-int orc_abi_version(void) { return 1; }
+int orc_abi_version(void) { return 2; }

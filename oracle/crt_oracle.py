@@ -65,8 +65,46 @@ def _lib():
     lib.orc_convert_scale_abs_f64.argtypes = [dp, up, ctypes.c_size_t, ctypes.c_float]
     lib.orc_add_weighted_f32.argtypes = [fp, ctypes.c_float, fp, ctypes.c_float, fp, ctypes.c_size_t]
     lib.orc_add_weighted_f64.argtypes = [dp, ctypes.c_double, dp, ctypes.c_double, dp, ctypes.c_size_t]
+    lib.orc_sepblur_f32_variant.argtypes = [fp, fp, fp, ci, ci, ci, fp, ci, fp, ci, ci, ci]
+    lib.orc_remap_bilinear_f64_fma.argtypes = [dp, dp, ci, ci, ci, fp, fp]
+    lib.orc_convert_scale_abs_f64_dbl.argtypes = [dp, up, ctypes.c_size_t, ctypes.c_float]
     _LIB = lib
     return lib
+
+
+# Which restated OpenCV accumulation form the cv2 stand-ins below use.  The ORACLE is the default (all zeros); tests
+# switch the other forms in through `opencv_variant` to measure the spread around it (crt_oracle.c, "ALTERNATIVE
+# ACCUMULATION FORMS").  blur_row / blur_col: modes of orc_sepblur_f32_variant; remap_fma: contracted bilinear sum for
+# CV_64F images; csa_double: convertScaleAbs of a CV_64F image multiplied in double (scalar tail of cvtabs_32f).
+VARIANT = {"blur_row": 0, "blur_col": 0, "remap_fma": 0, "csa_double": 0}
+OPENCV_VARIANTS = {
+    "oracle (RowFilter fma | ColumnFilter fma)": {},
+    "SymmColumnFilter fma": {"blur_col": 1},
+    "SymmColumnFilter mul+add": {"blur_col": 2, "blur_row": 1},
+    "ColumnFilter mul+add (SSE baseline)": {"blur_col": 3, "blur_row": 1},
+    "SymmRowSmall + SymmColumn fma": {"blur_row": 2, "blur_col": 1},
+    "SymmRowSmall + SymmColumn mul+add": {"blur_row": 3, "blur_col": 2},
+    "remap contracted (fma)": {"remap_fma": 1},
+    "convertScaleAbs in double": {"csa_double": 1},
+    "all alternatives at once": {"blur_row": 3, "blur_col": 2, "remap_fma": 1, "csa_double": 1},
+}
+
+
+class opencv_variant:
+    """with opencv_variant(blur_col=1): ... — run the restated chain with another of OpenCV's accumulation forms."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = dict(VARIANT)
+        VARIANT.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        VARIANT.clear()
+        VARIANT.update(self.old)
+        return False
 
 
 def _fp(a):
@@ -127,7 +165,11 @@ def gaussian_blur(src: np.ndarray, ksize: Tuple[int, int], sigma_x: float, sigma
     cn = 1 if src.ndim == 2 else src.shape[2]
     dst = np.empty_like(src)
     tmp = np.empty_like(src)
-    _lib().orc_sepblur_f32(_fp(src), _fp(dst), _fp(tmp), h, w, cn, _fp(kx), len(kx), _fp(ky), len(ky))
+    if VARIANT["blur_row"] or VARIANT["blur_col"]:
+        _lib().orc_sepblur_f32_variant(_fp(src), _fp(dst), _fp(tmp), h, w, cn, _fp(kx), len(kx), _fp(ky), len(ky),
+                                       VARIANT["blur_row"], VARIANT["blur_col"])
+    else:
+        _lib().orc_sepblur_f32(_fp(src), _fp(dst), _fp(tmp), h, w, cn, _fp(kx), len(kx), _fp(ky), len(ky))
     return dst
 
 
@@ -172,7 +214,7 @@ def remap_bilinear(img: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.
     if img.dtype == np.float64:
         src = np.ascontiguousarray(img)
         dst = np.empty_like(src)
-        _lib().orc_remap_bilinear_f64(_dp(src), _dp(dst), h, w, cn, _fp(mx), _fp(my))
+        (_lib().orc_remap_bilinear_f64_fma if VARIANT["remap_fma"] else _lib().orc_remap_bilinear_f64)(_dp(src), _dp(dst), h, w, cn, _fp(mx), _fp(my))
     else:
         src = np.ascontiguousarray(img, np.float32)
         dst = np.empty_like(src)
@@ -211,7 +253,7 @@ def convert_scale_abs(img: np.ndarray, alpha: float = 255.0) -> np.ndarray:
     out = np.empty(img.shape, np.uint8)
     if img.dtype == np.float64:
         a = np.ascontiguousarray(img)
-        _lib().orc_convert_scale_abs_f64(_dp(a), out.ctypes.data_as(up), a.size, alpha)
+        (_lib().orc_convert_scale_abs_f64_dbl if VARIANT["csa_double"] else _lib().orc_convert_scale_abs_f64)(_dp(a), out.ctypes.data_as(up), a.size, alpha)
     else:
         a = np.ascontiguousarray(img, np.float32)
         _lib().orc_convert_scale_abs_f32(_fp(a), out.ctypes.data_as(up), a.size, alpha)

@@ -78,6 +78,8 @@ SYMBOLS = {
     "crtfx_warp_map": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "crtfx_resize_state": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "crtfx_scanline_plane": (ctypes.c_int, [_vp] + [ctypes.c_double] * 5 + [_vp, _vp]),
+    "crtfx_set_option": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "crtfx_debug_buffer": (ctypes.c_int, [_vp, _vp]),
     "crtfx_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "crtfx_profile_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "crtfx_host_blur_row": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),

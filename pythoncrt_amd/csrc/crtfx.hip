@@ -32,24 +32,27 @@ struct crtfx_ctx {
     int pix_fmt = CRTFX_PIX_U8;
     bool params_set = false;
     KParams kp{};
-    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts;
+    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts, trash;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
     int group_seg = 128;             // rows per block when a full group is launched (plan_grid)
-    int seg_for[MAX_GROUP + 1] = {0, 0, 0, 0, 0};   // planned rows per block for a (partial) group of g frames
+    int seg_for[3][MAX_GROUP + 1] = {};             // planned rows per block for a (partial) group of g frames, per kernel build (runtime gates / folded / cc)
     // two-stream overlap of k_warp(n) with k_phosphor(n+1): side stream, per-slot events, 2 scratch slots
     bool overlap = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
     bool ev_k2_pending[2] = {false, false};
     int seg_rows = 0;                // rows per k_phosphor block
-    unsigned long long* dbg = nullptr;   // CRTFX_STAMP builds: CRTFX_DBG_PTR env hands in a device buffer
-    bool force_generic = false;      // CRTFX_FORCE_GENERIC=1: always take the LDS-ring kernel (tests)
-    int warp_rows = 2;               // CRTFX_WARP_ROWS=1|2: output rows per k_warp_lean thread
-    int point_tiles = 0;             // CRTFX_POINT_TILES=n: rows (wavefronts) per k_point block, 1..16 (0 = 16)
-    bool force_runtime_flags = false; // CRTFX_FORCE_RUNTIME_FLAGS=1: never take a gate-folded instantiation (tests)
+    unsigned long long* dbg = nullptr;   // -DCRTFX_STAMP builds only: crtfx_debug_buffer hands in a device buffer
+    bool force_generic = false;      // CRTFX_OPT_FORCE_GENERIC: always take the LDS-ring kernel (tests)
+    int warp_rows = 2;               // CRTFX_OPT_WARP_ROWS = 1|2|4: output rows per k_warp_lean thread
+    int point_tiles = 0;             // CRTFX_OPT_POINT_TILES = n: rows (wavefronts) per k_point block, 1..16 (0 = default)
+    bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
+    bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
+    int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
+    bool debug_plan = false;
     std::string err;
     // profiling
     bool prof = false;
@@ -62,6 +65,19 @@ struct crtfx_ctx {
 };
 
 namespace {
+
+// crtfx_create / crtfx_destroy / crtfx_set_params work on the ctx's device and leave the calling thread's current
+// device as they found it (a process that drives several GPUs keeps its own hipSetDevice state).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
 
 int fail(crtfx_ctx* c, int code, const char* fmt, ...) {
     if (c) {
@@ -162,7 +178,6 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bo
 // blocks 103 us; 184 rows x 720 blocks 118 us; 96 rows x 1380 blocks 119 us.  1080p, R=4: 32 rows x 1020
 // blocks 29 us against 34 us at 64 rows — filling the slots beats the extra halo rows; floor 24 rows.
 int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
-    if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) return ((v + NB - 1) / NB) * NB; }   // tuning experiments
     const int strips = (W + TW - 1) / TW;
     const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
     int bpc = (int)(163840 / lds);
@@ -185,12 +200,12 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
 // measured landscape (4K, R = 9: g=1/seg=128 -> 19 it/frame = 89 us; g=2/seg=256 -> 17.5 = 82.5 us, the short
 // last-segment blocks freeing slots for the overflow; g=2/seg=240 -> two full rounds = 103 us).
 struct GridPlan { int g, seg; };
-GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed) {
+GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed, bool cc = false) {
     const int strips = (W + TW - 1) / TW;
     const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
-    const size_t lds = phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
+    const size_t lds = cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
     int bpc = (int)(163840 / lds);
-    const int by_regs = rr_min_waves(Rk, folded);      // a block = one wave per SIMD
+    const int by_regs = cc ? cc_min_waves(Rk) : rr_min_waves(Rk, folded);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
     const int slots = bpc * 256;
     const int hcap = ((H + NB - 1) / NB) * NB;
@@ -259,15 +274,20 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
     if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
     for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
-    if (!c->seg_for[g]) c->seg_for[g] = plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g).seg;   // partial last group / single frames: planned once
-    const int seg = c->seg_for[g];
+    // the column-owner kernel takes the full-chain launches that park a pre-warp image (warp and / or persistence behind them)
+    bool cc = folded && !c->no_cc;
+    for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
+    int& seg_slot = c->seg_for[cc ? 2 : (folded ? 1 : 0)][g];
+    if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, cc).seg;   // planned once per (kernel build, group size)
+    const int seg = seg_slot;
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const int variant = c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0);
+    const int variant = cc ? (c->pix_fmt == CRTFX_PIX_F16 ? 5 : 4) : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0));
     const bool runtime = !folded;
+    const size_t lds = cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
+                          : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
     ProfEv pe(c, 0, g);
-    table[R](c->kp, kg, seg, dim3(strips, segs, g), phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr),
-             s, variant, pe.e0, pe.e1);
+    table[R](c->kp, kg, seg, dim3(strips, segs, g), lds, s, variant, pe.e0, pe.e1);
 }
 
 // Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
@@ -433,36 +453,22 @@ int crtfx_create(int device, int height, int width, int pix_fmt, crtfx_ctx** out
     if (pix_fmt != CRTFX_PIX_U8 && pix_fmt != CRTFX_PIX_F16) return CRTFX_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return CRTFX_E_HIP;
-    if (hipSetDevice(device) != hipSuccess) return CRTFX_E_HIP;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return CRTFX_E_HIP;
     crtfx_ctx* c = new (std::nothrow) crtfx_ctx();
     if (!c) return CRTFX_E_NOMEM;
     c->device = device; c->H = height; c->W = width; c->pix_fmt = pix_fmt;
     if (hipMalloc((void**)&c->pre, (size_t)height * width * 3 * sizeof(float)) != hipSuccess) { delete c; return CRTFX_E_NOMEM; }
     c->seg_rows = pick_seg_rows(height, width, 9, pix_fmt);
-    if (const char* ov = getenv("CRTFX_OVERLAP")) c->overlap = ov[0] == '1';
-    if (c->overlap) {
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->overlap = false;
-        for (int i = 0; i < 2 && c->overlap; ++i)
-            if (hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming) != hipSuccess) c->overlap = false;
-    }
-    const char* fg = getenv("CRTFX_FORCE_GENERIC");
-    c->force_generic = fg && fg[0] == '1';
-    if (const char* pt = getenv("CRTFX_POINT_TILES")) c->point_tiles = atoi(pt);
-    if (const char* wr = getenv("CRTFX_WARP_ROWS")) { const int v = atoi(wr); c->warp_rows = (v == 1 || v == 4) ? v : 2; }
-    const char* fr = getenv("CRTFX_FORCE_RUNTIME_FLAGS");
-    c->force_runtime_flags = fr && fr[0] == '1';
-    const char* dp = getenv("CRTFX_DBG_PTR");
-    if (dp) c->dbg = reinterpret_cast<unsigned long long*>(strtoull(dp, nullptr, 0));
     *out_ctx = c;
     return CRTFX_OK;
 }
 
 int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
+    for (DevBuf* b : {&c->trash, &c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
                       &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
@@ -475,7 +481,8 @@ int crtfx_destroy(crtfx_ctx* c) {
 int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     if (!c || !p) return CRTFX_E_INVALID;
     if (p->size != sizeof(crtfx_params)) return fail(c, CRTFX_E_INVALID, "crtfx_params.size %u != %zu", p->size, sizeof(crtfx_params));
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    HIP_TRY(c, guard.err);
     HIP_TRY(c, hipDeviceSynchronize());   // tables may be in use by enqueued work
     const uint32_t fl = p->flags;
     const int H = c->H, W = c->W;
@@ -549,6 +556,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         if ((rc = upload(c, c->consts, cst, sizeof(cst)))) return rc;
         k.consts = (const float*)c->consts.p;
     }
+    if (!c->trash.p) {      // where k_phosphor_cc's branch-free stores of rows / lanes outside the frame land; never read
+        HIP_TRY(c, hipMalloc(&c->trash.p, (size_t)CC_TRASH_WAVES * 64 * sizeof(float)));
+        c->trash.bytes = (size_t)CC_TRASH_WAVES * 64 * sizeof(float);
+    }
+    k.trash = (float*)c->trash.p;
     k.vig_nx2 = (const double*)c->nx2.p; k.vig_ny2 = (const double*)c->ny2.p;
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
@@ -572,9 +584,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
         const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
-        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap);
-        if (const char* e = getenv("CRTFX_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= MAX_GROUP) { gp.g = v; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, v); } }
-        if (const char* e = getenv("CRTFX_SEG_ROWS")) { const int v = atoi(e); if (v >= NB) gp.seg = ((v + NB - 1) / NB) * NB; }
+        // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
+        const bool cc_plan = folded_plan && !c->no_cc && (k.flags & CRTFX_F_WARP);
+        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_plan);
+        if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) { gp.g = c->opt_group; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, gp.g); }
+        if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;
         const int need = c->overlap ? 2 * gp.g : gp.g;
         if (need > c->pre_frames) {
             (void)hipFree(c->pre);
@@ -584,9 +598,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         }
         c->group_max = gp.g;
         c->group_seg = gp.seg;
-        if (getenv("CRTFX_DEBUG_PLAN")) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block\n", W, H, R, gp.g, gp.seg);
-        for (int g = 1; g <= MAX_GROUP; ++g) c->seg_for[g] = 0;
-        c->seg_for[gp.g] = gp.seg;
+        if (c->debug_plan) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block%s\n", W, H, R, gp.g, gp.seg, cc_plan ? " (k_phosphor_cc)" : "");
+        for (int b = 0; b < 3; ++b) for (int g = 1; g <= MAX_GROUP; ++g) c->seg_for[b][g] = 0;
+        c->seg_for[cc_plan ? 2 : (folded_plan ? 1 : 0)][gp.g] = gp.seg;
     }
 
     if (fl & CRTFX_F_BLOOM) {
@@ -844,6 +858,44 @@ int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, cons
             row_out[(size_t)x * cn + ch] = s;
         }
     return CRTFX_OK;
+}
+
+int crtfx_set_option(crtfx_ctx* c, int option, int value) {
+    if (!c) return CRTFX_E_INVALID;
+    switch (option) {
+    case CRTFX_OPT_FORCE_GENERIC: c->force_generic = value != 0; break;
+    case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
+    case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
+    case CRTFX_OPT_GROUP: if (value < 0 || value > MAX_GROUP) return fail(c, CRTFX_E_INVALID, "group %d outside 0..%d", value, MAX_GROUP); c->opt_group = value; break;
+    case CRTFX_OPT_SEG_ROWS: if (value < 0) return fail(c, CRTFX_E_INVALID, "seg_rows %d < 0", value); c->opt_seg_rows = value ? ((value + NB - 1) / NB) * NB : 0; break;
+    case CRTFX_OPT_WARP_ROWS: if (value != 1 && value != 2 && value != 4) return fail(c, CRTFX_E_INVALID, "warp rows must be 1, 2 or 4"); c->warp_rows = value; break;
+    case CRTFX_OPT_POINT_TILES: if (value < 0 || value > 16) return fail(c, CRTFX_E_INVALID, "point tiles outside 0..16"); c->point_tiles = value; break;
+    case CRTFX_OPT_DEBUG_PLAN: c->debug_plan = value != 0; break;
+    case CRTFX_OPT_OVERLAP:
+        if (value && !c->side) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming));
+            }
+        }
+        c->overlap = value != 0;
+        break;
+    default: return fail(c, CRTFX_E_INVALID, "unknown option %d", option);
+    }
+    c->params_set = false;      // launch shapes are planned in crtfx_set_params: the caller sets the parameters again
+    return CRTFX_OK;
+}
+
+int crtfx_debug_buffer(crtfx_ctx* c, void* dev_ptr) {
+#ifdef CRTFX_STAMP
+    if (!c) return CRTFX_E_INVALID;
+    c->dbg = static_cast<unsigned long long*>(dev_ptr);
+    return CRTFX_OK;
+#else
+    (void)dev_ptr;
+    return fail(c, CRTFX_E_UNSUPPORTED, "phase stamps need a -DCRTFX_STAMP build of libcrtfx");
+#endif
 }
 
 int crtfx_profile_enable(crtfx_ctx* c, int on) {

@@ -64,7 +64,9 @@ struct KParams {
     int hw, hh;                                                         // half-res size (max(1, W//2), max(1, H//2))
     float* ds;                                                          // half-res thresholded source, hh x hw x 3 float32 (ctx scratch)
     const float* consts;                                                // ctx-owned: float 1,1,1,1 then 112 zero bytes — a valid address for loads a disabled stage would make (k_point_sel)
+    float* trash;                                                       // ctx-owned, CC_TRASH_WAVES x 64 floats, never read: where k_phosphor_cc's branch-free stores of rows / lanes outside the frame go
 };
+constexpr int CC_TRASH_WAVES = 1024;
 
 struct KFrame {
     const uint8_t* __restrict__ in;
@@ -464,7 +466,11 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
         double v0 = 0, v1 = 0, v2 = 0;
         if (LEAN || live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);   // lean callers pass valid (replicated) pixels in dead lanes: no branch
         if (O.pre) {
+#ifdef CC_EXP_NOSTORE
+            if (v0 == -12345.0) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
+#else
             if (live) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
+#endif
             return;
         }
         if (live) packed = commit_pixel<double, COMMIT>(O, pix, v0, v1, v2);
@@ -1296,6 +1302,362 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
 #endif
 }
 #undef TAP
+
+// ---------------------------------------------------------------------------------------
+// k_phosphor_cc — the full-chain gate set (SF_FULL: Gaussian bloom, triad LUTs, row scanlines, analytic vignette,
+// grain) of k_phosphor_rr for launches that park a float32 pre-warp image (warp and / or persistence behind it).
+// Same arithmetic, expression for expression (tests/test_parity_gpu.py::test_kernel_variants_agree holds the builds
+// to identical bits); what changes is who does what, and that each phase of a wave is ONE basic block.  The PMC passes on
+// k_phosphor_rr showed a wave issuing one instruction per ~14 cycles: every `if` around a row or an item ends in an
+// s_waitcnt, so LDS round trips were paid one after the other, wave 3 idled through the V pass, and the blur went back
+// to LDS to be re-read by another thread.
+//
+//   CONSUMER waves 0-2: thread f owns float f of the strip's 192-float interleaved RGB row segment (pixel f / 3,
+//   channel f % 3) in the V pass AND in the pointwise tail, eight rows at a time, everything in registers between them:
+//     phase 1   centre samples of block n-1 (LDS -> a1 table, issued first) | C1(n-1) V pass on the register window |
+//               A(n): its share of the prefetched halo bytes -> staging tile | prefetch of block n+1
+//     phase 2   C2(n-1): img + s*blur, triad LUT pair, scanline, * vignette, + grain for the eight rows stage by stage,
+//               eight branch-free stores (256 contiguous bytes per wave; rows / lanes outside the frame go to a trash
+//               line, so the stores sit in the same basic block and the compiler counts them exactly in vmcnt) | B(n)
+//   HELPER wave 3: lane = pixel column:
+//     phase 1   V(n-1): float64 vignette gain of the block's 8 x 64 pixels -> LDS | its share of A(n) | prefetch
+//     phase 2   N(n): grain N(0,1) * scale of the NEXT block's 8 x 64 pixels -> LDS (double-buffered) | its share of B(n)
+//   two barriers per eight rows, as before.  The two roles run separate copies of the loop (same trip count, same
+//   barriers): no role test inside a phase.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr int cc_sws(int R) { return (rr_swp(R) + 31) & ~31; }
+__host__ __device__ constexpr int cc_cring_words(int R, int pix) { return pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW; }
+// LDS words: staging, ONE H-row tile, LUTs, centre ring, a1 table (uint8), vignette tile (f64), two grain tiles (f32), row table
+__host__ __device__ constexpr int cc_lds_words(int R, int pix) {
+    return NB * 3 * cc_sws(R) + NB * 3 * TW + 2 * LUT_STRIDE + cc_cring_words(R, pix) + (pix ? 0 : 256) + NB * TW * 2 + 2 * NB * TW + 16 * 4;
+}
+__host__ __device__ constexpr int cc_min_waves(int R) { return R <= 12 ? 4 : (R <= 20 ? 3 : 2); }
+#ifndef CC_A3
+#define CC_A3(na) ((na) / 5)                // A-phase wave-items (64 staged pixels each) of the helper wave; waves 0-2 share the rest
+#endif
+#ifndef CC_B3
+#define CC_B3 1                             // B-phase wave-items (64 x 4 H-pass outputs each) of the helper wave, of 6; waves 0-2 share the rest
+#endif
+
+template <int RT, int PIX>
+__global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KParams Pin, KGroup G, int seg_rows) {
+    const KFrame F = G.f[blockIdx.z];
+    const KOut O = G.o[blockIdx.z];
+    KParams P = Pin;
+    P.flags = SF_FULL;
+    P.pix = PIX;
+    extern __shared__ float4 smem4[];
+    float* smem = reinterpret_cast<float*>(smem4);
+    constexpr int R = RT, K = 2 * R + 1;
+    constexpr int pad = rr_pad(R);
+    constexpr int SWP = rr_swp(R);
+    constexpr int SWS = cc_sws(R);
+    constexpr int L = 2 * R + NB;
+    constexpr int CR = rr_cring(R);
+    constexpr int NA = (NB * SWP + 63) / 64;             // A-phase wave-items
+    constexpr int A3 = CC_A3(NA);                        // ... of the helper wave (the last A3 items)
+    constexpr int AO = (NA - A3 + 2) / 3;                // ... of each consumer wave (items wave, wave + 3, ...)
+    constexpr int NBI = NB * 48 / 64;                    // B-phase wave-items (6)
+    constexpr int B3 = CC_B3;
+    constexpr int BO = (NBI - B3 + 2) / 3;
+    constexpr int HT = NB * 3 * TW;
+    constexpr bool NLUT = PIX == 0;
+    float* stg = smem;                                   // [NB][3][SWS]
+    float* hrow = stg + NB * 3 * SWS;                    // [NB][TW][3]  interleaved like the image row
+    float* lut = hrow + HT;                              // [2][LUT_STRIDE]
+    uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);    // uint8: [CR][TW] packed r|g<<8|b<<16.  half: [CR][TW][3] uint16
+    uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
+    float* nlut = reinterpret_cast<float*>(cring + cc_cring_words(R, PIX));           // [256] u / 255.0 (uint8 frames)
+    double* gvig = reinterpret_cast<double*>(nlut + (NLUT ? 256 : 0));               // [NB][TW]
+    float* gn = reinterpret_cast<float*>(gvig + NB * TW);                            // [2][NB][TW]
+    uint32_t* rowtab = reinterpret_cast<uint32_t*>(gn + 2 * NB * TW);                // [16][4]: scan gain bits, ny2 lo, ny2 hi, -
+
+    const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int tid = (threadIdx.x + ((wg_lin & 3) << 6)) & (RR_THREADS - 1);          // roles rotate over the SIMDs with the dispatch number
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int H = P.H, W = P.W;
+    const int x0 = blockIdx.x * TW;
+    const int y_begin = blockIdx.y * seg_rows;
+    const int y_end = min(H, y_begin + seg_rows);
+    if (y_begin >= H) return;
+
+    for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    if constexpr (NLUT) { if (tid < 256) nlut[tid] = norm_u8((uint32_t)tid); }
+    const float* taps = P.taps;
+#define TAP(k) taps[(k) <= R ? (k) : 2 * R - (k)]
+    const uint32_t row_elems = (uint32_t)W * 3u;
+    const int n_iter = (y_end + R - (y_begin - R) + NB - 1) / NB;                    // loop trips (same for both roles)
+#ifdef CRTFX_STAMP
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+
+    // ---- pieces shared by the two roles (instantiated once per role: item counts are compile-time there) -------------
+    // source element offsets of A-phase wave-item q for this lane (block-invariant)
+    auto a_offsets = [&](int q, uint32_t& o_r, uint32_t& o_g, uint32_t& o_b) {
+        const int it = min((q << 6) + lane, NB * SWP - 1);     // lanes past the tile's last item redo it (same loads, same LDS stores)
+        const int i = it - (it / SWP) * SWP;
+        const int x = min(max(x0 - pad + i, 0), W - 1);
+        int xr = x, xb = x;
+        if (P.ab != 0) { xr = wrap(x - P.ab, W); xb = wrap(x + P.ab, W); }      // ref:573-575
+        o_r = (uint32_t)xr * 3u; o_g = (uint32_t)x * 3u + 1u; o_b = (uint32_t)xb * 3u + 2u;
+    };
+    auto a_load = [&](int q, int hb, uint32_t o_r, uint32_t o_g, uint32_t o_b) -> RawRGB {
+        const int it = min((q << 6) + lane, NB * SWP - 1);
+        const int y = min(max(hb + it / SWP, 0), H - 1);                          // BORDER_REPLICATE
+        const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
+        return load_raw(PIX, F.in, ro + o_r, ro + o_g, ro + o_b);
+    };
+    auto a_stage = [&](int q, int crow0, RawRGB v) {
+        const int it = min((q << 6) + lane, NB * SWP - 1);
+        const int j = it / SWP, i = it - j * SWP;
+        float r, g, b;
+        if constexpr (NLUT) { r = nlut[v.r]; g = nlut[v.g]; b = nlut[v.b]; }
+        else { r = norm_px(PIX, v.r); g = norm_px(PIX, v.g); b = norm_px(PIX, v.b); }
+        if (i >= pad && i < pad + TW) {
+            int cr = crow0 + j;
+            cr = cr >= CR ? cr - CR : cr;
+            if constexpr (PIX) { uint16_t* cp = cring16 + (cr * TW + (i - pad)) * 3; cp[0] = (uint16_t)v.r; cp[1] = (uint16_t)v.g; cp[2] = (uint16_t)v.b; }
+            else cring[cr * TW + (i - pad)] = v.r | (v.g << 8) | (v.b << 16);
+        }
+        float* sp = stg + (j * 3) * SWS + i;
+        sp[0] = r; sp[SWS] = g; sp[2 * SWS] = b;
+    };
+    auto b_item = [&](int q) {                                  // H pass of wave-item q: 64 lanes x 4 adjacent pixels of one channel and row
+        const int it = (q << 6) + lane;
+        const int j = it / 48, rem = it - j * 48;
+        const int c = rem >> 4, gq = rem & 15;
+        const lds_cv_f32x4* srow = (const lds_cv_f32x4*)smem4 + ((j * 3 + c) * (SWS / 4) + gq);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        constexpr int off = pad - R;
+#pragma unroll
+        for (int qq = 0; qq < (2 * pad + 4) / 4; ++qq) {
+            const f32x4 vv = srow[qq];
+            const float ve[4] = {vv[0], vv[1], vv[2], vv[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tt = 4 * qq + e - i - off;
+                    if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], TAP(tt), acc[i]);
+                }
+        }
+        float* hp = hrow + (j * TW + 4 * gq) * 3 + c;          // interleaved tile: four floats 12 bytes apart (48 lanes, 48 banks)
+        hp[0] = acc[0]; hp[3] = acc[1]; hp[6] = acc[2]; hp[9] = acc[3];
+    };
+
+    if (wave < 3) {
+        // =============================== CONSUMER: waves 0-2 ================================================================
+        const int f = wave * 64 + lane;
+        const int fcol = f / 3, fch = f - 3 * fcol;
+        const bool fin = x0 + fcol < W;
+        const float cm = P.triad_row[min(x0 + fcol, W - 1) * 3 + fch];           // a7 mask of this float
+        float* const trash = P.trash + (((uint32_t)wg_lin * 3u + (uint32_t)wave) & (CC_TRASH_WAVES - 1)) * 64 + lane;
+        float win[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) win[i] = 0.0f;
+        uint32_t offr[AO], offg[AO], offb[AO];
+        RawRGB raw[AO];
+#pragma unroll
+        for (int u = 0; u < AO; ++u) a_offsets(min(wave + 3 * u, NA - A3 - 1), offr[u], offg[u], offb[u]);
+        __syncthreads();                                // LUTs / a1 table visible
+#pragma unroll
+        for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), y_begin - R, offr[u], offg[u], offb[u]);
+        // eight stores behind the first prefetch, as in every later trip: the loop is entered with the same count of vector
+        // memory operations younger than the prefetched bytes as its back edge carries, so A's s_waitcnt vmcnt leaves
+        // exactly the stores in flight
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *(volatile float*)trash = 0.0f;
+        int crow0 = 0, c2row0 = NB;
+        int hb = y_begin - R;
+        for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
+                                        c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
+            // ---- phase 1 ----
+            float v[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {              // centre sample of output row hb - NB - R + j (a1; a2 is in the parked sample); garbage in trip 0
+                int cr = c2row0 + j;
+                cr = cr >= CR ? cr - CR : cr;
+                if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
+                else v[j] = nlut[(cring[cr * TW + fcol] >> (8 * fch)) & 255u];
+            }
+            float blur[NB];
+            {
+                const float* hcol = hrow + f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
+                    blur[j] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < 2 * R; ++i) win[i] = win[i + NB];
+            }
+            STAMP(4);
+#pragma unroll
+            for (int u = 0; u < AO; ++u) a_stage(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u]);
+#pragma unroll
+            for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hb + NB, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
+            STAMP(0);
+            __syncthreads();
+            STAMP(1);
+            // ---- phase 2: C2 of block n-1 (output rows hb - NB - R + j), stage by stage over the eight rows ----
+            const float* gt = gn + ((n & 1) ^ 1) * NB * TW;
+            const int yb = hb - NB - R;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);          // ref:611
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = lut[lut_index_unit(v[j])] * cm;                      // ref:250-252
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = lut[LUT_STRIDE + lut_index(v[j])];                   // ref:261-262
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const float sl = __uint_as_float(rowtab[((yb + j - y_begin) & 15) * 4]);
+                const float r = clip01(v[j] * sl);                                                  // ref:617-624
+                double d = (double)r * gvig[j * TW + fcol];                                         // ref:626-628 (gain in [0,1]: no clip)
+                d = clip01(d + (double)gt[j * TW + fcol]);                                          // ref:646-647
+                v[j] = (float)d;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int y = yb + j;
+                float* dst = O.pre + (((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u + (uint32_t)f);
+                dst = (y >= y_begin && y < y_end && fin) ? dst : trash;
+#ifdef CC_EXP_NOSTORE
+                asm volatile("" : "+v"(v[j]));
+                (void)dst;
+#else
+                *dst = v[j];
+#endif
+            }
+            STAMP(6);
+#pragma unroll
+            for (int u = 0; u < BO; ++u) { const int q = wave + 3 * u; if (q < NBI - B3) b_item(q); }
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+        }
+        // ---- drain: C1 and C2 of the last block ----
+        {
+            float v[NB], blur[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int cr = c2row0 + j;
+                cr = cr >= CR ? cr - CR : cr;
+                if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
+                else v[j] = nlut[(cring[cr * TW + fcol] >> (8 * fch)) & 255u];
+            }
+            const float* hcol = hrow + f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
+                blur[j] = acc;
+            }
+            __syncthreads();
+            const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
+            const int yb = hb - NB - R;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = lut[lut_index_unit(v[j])] * cm;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) v[j] = lut[LUT_STRIDE + lut_index(v[j])];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int y = yb + j;
+                const float sl = __uint_as_float(rowtab[((y - y_begin) & 15) * 4]);
+                const float r = clip01(v[j] * sl);
+                double d = (double)r * gvig[j * TW + fcol];
+                d = clip01(d + (double)gt[j * TW + fcol]);
+                if (y >= y_begin && y < y_end && fin) O.pre[((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u + (uint32_t)f] = (float)d;
+            }
+        }
+    } else {
+        // =============================== HELPER: wave 3 ======================================================================
+        const int xg = x0 + lane;
+        const double cnx2 = P.vig_nx2[min(xg, W - 1)];
+        constexpr int A3R = A3 > 0 ? A3 : 1;
+        uint32_t offr[A3R], offg[A3R], offb[A3R];
+        RawRGB raw[A3R];
+#pragma unroll
+        for (int u = 0; u < A3; ++u) a_offsets(NA - A3 + u, offr[u], offg[u], offb[u]);
+        __syncthreads();
+        float pf_scan = 1.0f;
+        double pf_ny2 = 0.0;
+        auto prefetch = [&](int hbn) {
+            const int yr = hbn - R + lane;
+            if (lane < NB && yr >= y_begin && yr < y_end) { pf_scan = F.scan_row[yr]; pf_ny2 = P.vig_ny2[yr]; }
+#pragma unroll
+            for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hbn, offr[u], offg[u], offb[u]);
+        };
+        prefetch(y_begin - R);
+        int crow0 = 0;
+        int hb = y_begin - R;
+        for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB) {
+            // ---- phase 1: a9 vignette gain of block n-1's pixels; row constants of block n; its share of A(n) ----
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int y = min(max(hb - NB - R + j, y_begin), y_end - 1);       // rows outside the segment: any valid row, never consumed
+                const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 4;
+                gvig[j * TW + lane] = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
+            }
+            STAMP(4);
+            {
+                const int yr = hb - R + lane;
+                if (lane < NB && yr >= y_begin && yr < y_end) {
+                    uint32_t* rt = rowtab + ((yr - y_begin) & 15) * 4;
+                    rt[0] = __float_as_uint(pf_scan); rt[1] = (uint32_t)__double2loint(pf_ny2); rt[2] = (uint32_t)__double2hiint(pf_ny2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < A3; ++u) a_stage(NA - A3 + u, crow0, raw[u]);
+            prefetch(hb + NB);
+            STAMP(0);
+            __syncthreads();
+            STAMP(1);
+            // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip); its share of B(n) ----
+            float* gw = gn + (n & 1) * NB * TW;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int y = min(max(hb - R + j, 0), H - 1);
+#ifdef CC_EXP_CHEAPG
+                const float z = __uint_as_float(0x3f000000u | (((uint32_t)y * (uint32_t)W + (uint32_t)xg) & 0xffffu));
+#else
+                const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
+#endif
+                gw[j * TW + lane] = z * P.noise_scale;
+            }
+            STAMP(6);
+#pragma unroll
+            for (int u = 0; u < B3; ++u) b_item(NBI - B3 + u);
+            STAMP(2);
+            __syncthreads();
+            STAMP(3);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int y = min(max(hb - NB - R + j, y_begin), y_end - 1);
+            const uint32_t* rt = rowtab + ((y - y_begin) & 15) * 4;
+            gvig[j * TW + lane] = vignette_gain(P, cnx2, __hiloint2double((int)rt[2], (int)rt[1]));
+        }
+        __syncthreads();
+    }
+#ifdef CRTFX_STAMP
+    if (O.dbg && lane == 0) {
+        unsigned long long* d = O.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = stamp_sum[i];
+    }
+#endif
+#undef TAP
+}
 
 // ---------------------------------------------------------------------------------------
 // k_warp — barrel warp gather (ref:331-348 + cv2.remap INTER_LINEAR / BORDER_CONSTANT 0),

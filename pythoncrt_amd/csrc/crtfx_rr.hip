@@ -1,5 +1,6 @@
 // crtfx_rr.hip — instantiations of k_phosphor_rr for ONE radius (-DRR_R=n): the gate-folded
 // full-chain variant and the runtime-flag variant.  Compiled once per radius, in parallel.
+#include <atomic>
 #include "crtfx_internal.h"
 
 #ifndef RR_R
@@ -13,32 +14,36 @@ namespace crtfx {
 
 void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_rows, dim3 grid, size_t lds,
                                  hipStream_t s, int variant, hipEvent_t e0, hipEvent_t e1) {
-    if (variant == 2)       // half frames, full-chain gates
+    if (variant == 4)       // full-chain gates, pre-warp image out: the column-owner kernel (uint8 frames)
+        CRTFX_LAUNCH((k_phosphor_cc<RR_R, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    else if (variant == 5)  // ... half frames
+        CRTFX_LAUNCH((k_phosphor_cc<RR_R, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    else if (variant == 2)       // half frames, full-chain gates
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else if (variant == 1)
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     else if (variant == 3) {     // half frames, runtime gates
         if (lds > 65536) {
-            static bool raised16[64] = {};
+            static std::atomic<bool> raised16[64];      // zero-initialised; set once per device, from any thread
             int dev = 0;
             (void)hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64 || !raised16[dev]) {
+            if (dev < 0 || dev >= 64 || !raised16[dev].load(std::memory_order_acquire)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (dev >= 0 && dev < 64) raised16[dev] = true;
+                if (dev >= 0 && dev < 64) raised16[dev].store(true, std::memory_order_release);
             }
         }
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     }
     else {
         if (lds > 65536) {      // large radii park up to 35 KB of graded centre pixels: above the default dynamic-LDS limit
-            static bool raised[64] = {};      // per device: one process may drive several GPUs
+            static std::atomic<bool> raised[64];      // zero-initialised; set once per device, from any thread      // per device: one process may drive several GPUs
             int dev = 0;
             (void)hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64 || !raised[dev]) {
+            if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (dev >= 0 && dev < 64) raised[dev] = true;
+                if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
             }
         }
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);

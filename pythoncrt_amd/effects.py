@@ -86,6 +86,7 @@ class VignetteMask:
 # mask is then looked at again).  At most four arrays are held.
 _RECOGNISED = {}      # (kind, id(array)) -> (array, fingerprint, descriptor or False)
 _RECOGNISED_MAX = 4
+_RECOGNISED_LOCK = threading.Lock()     # apply_static_effects is called from the reference's two worker threads
 
 
 def _fingerprint(a: np.ndarray) -> int:
@@ -94,17 +95,20 @@ def _fingerprint(a: np.ndarray) -> int:
 
 
 def _lookup(kind, mask):
-    e = _RECOGNISED.get((kind, id(mask)))
+    with _RECOGNISED_LOCK:
+        e = _RECOGNISED.get((kind, id(mask)))
     if e is not None and e[0] is mask and e[1] == _fingerprint(mask):
         return e[2]
     return None
 
 
 def _remember(kind, mask, value):
-    _RECOGNISED.pop((kind, id(mask)), None)
-    while len(_RECOGNISED) >= _RECOGNISED_MAX:
-        _RECOGNISED.pop(next(iter(_RECOGNISED)))
-    _RECOGNISED[(kind, id(mask))] = (mask, _fingerprint(mask), value)
+    fp = _fingerprint(mask)
+    with _RECOGNISED_LOCK:
+        _RECOGNISED.pop((kind, id(mask)), None)
+        while len(_RECOGNISED) >= _RECOGNISED_MAX:
+            _RECOGNISED.pop(next(iter(_RECOGNISED)), None)
+        _RECOGNISED[(kind, id(mask))] = (mask, fp, value)
     return value
 
 
@@ -169,6 +173,13 @@ def _fresh_seed() -> int:
         return _seed_counter[0]
 
 
+# Testing / tuning switches handed to every ctx created from now on (crtfx_set_option; include/crtfx.h): e.g.
+# {"FORCE_GENERIC": 1}.  Empty in the product path; nothing reads the environment.
+DEBUG_OPTIONS = {}
+_OPTION_IDS = {"FORCE_GENERIC": 1, "FORCE_RUNTIME_FLAGS": 2, "NO_CC": 3, "GROUP": 4, "SEG_ROWS": 5, "WARP_ROWS": 6, "POINT_TILES": 7,
+               "OVERLAP": 8, "DEBUG_PLAN": 9}
+
+
 class Engine:
     """Owns a crtfx ctx, the host tables and the device-side per-frame scratch tensors."""
 
@@ -184,6 +195,8 @@ class Engine:
         if rc != _lib.OK:
             raise _lib.CrtfxError(rc, f"crtfx_create({device}, {h}, {w}) failed")
         self.ctx = ctx
+        for name, value in DEBUG_OPTIONS.items():
+            _lib.check(self.lib, ctx, self.lib.crtfx_set_option(ctx, _OPTION_IDS[name], int(value)))
         self.params_key = None
         self.keep = {}            # host arrays / device tensors the current params point at
         self.auto_frame = 0
@@ -413,7 +426,14 @@ class Settings:
         for f in self.FIELDS:
             v = getattr(self, f)
             if f in ("triad_mask", "vignette_mask") and v is not None:
-                v = v.key() if hasattr(v, "key") else ("array", id(v))
+                # a plain array / tensor mask is a per-pixel plane: keyed by identity AND a strided-sample fingerprint (or
+                # the tensor's version counter), so a mask rebuilt in place — or an id reused after a free — is uploaded again
+                if hasattr(v, "key"):
+                    v = v.key()
+                elif isinstance(v, torch.Tensor):
+                    v = ("tensor", id(v), v.data_ptr(), tuple(v.shape), v._version)
+                else:
+                    v = ("array", id(v), _fingerprint(np.asarray(v)) if np.asarray(v).ndim >= 2 else hash(np.asarray(v).tobytes()))
             out.append(v)
         return tuple(out)
 

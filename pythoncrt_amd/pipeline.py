@@ -200,23 +200,37 @@ class FramePipeline:
 # ---------------------------------------------------------------------------------------
 
 class GpuShardEngine:
-    def __init__(self, pipe: FramePipeline, chunk: int):
+    """Buffers of one rank's chunks.  `slots` = 2 double-buffers the per-frame local states and the output frames so that
+    round r+1's scan can be enqueued while round r's state frame is still travelling (ShardedRender overlap=True).
+    The float32 local states (chunk x H x W x 3 per slot — 288 GB of HBM is what lets a chunk cover the IIR's whole
+    settling time) are only allocated when the render has persistence."""
+
+    def __init__(self, pipe: FramePipeline, chunk: int, slots: int = 1):
         self.pipe = pipe
+        self.slots = int(slots)
         h, w = pipe.h, pipe.w
-        self.local = torch.empty((chunk, h, w, 3), dtype=torch.float32, device=pipe.device)
-        self.out = torch.empty((chunk, h, w, 3), dtype=pipe.dtype, device=pipe.device)
-        self.zero = torch.zeros((h, w, 3), dtype=torch.float32, device=pipe.device)
+        p = pipe.rs.persistence
+        self.local = [torch.empty((chunk, h, w, 3), dtype=torch.float32, device=pipe.device) for _ in range(self.slots)] if p > 0.0 else None
+        self.out_slots = [torch.empty((chunk, h, w, 3), dtype=pipe.dtype, device=pipe.device) for _ in range(self.slots)]
+        self.out = self.out_slots[0]
+        self.zero = torch.zeros((h, w, 3), dtype=torch.float32, device=pipe.device) if p > 0.0 else None
+        self.state = torch.empty((h, w, 3), dtype=torch.float32, device=pipe.device) if p > 0.0 else None
         self.records = {}
 
-    def local_scan(self, frames, first_index, clip_start):
+    def local_scan(self, frames, first_index, clip_start, slot: int = 0):
         n = frames.shape[0]
         recs = self.records.pop(first_index, None)
+        out = self.out_slots[slot % self.slots]
         if self.pipe.rs.persistence <= 0.0:
-            self.pipe.run(frames, first_index=first_index, out=self.out[:n], records=recs)
-            return None, self.out[:n]
-        state = None if clip_start else self.zero.clone()      # zero incoming state, blend from the first frame on
-        self.pipe.run(frames, first_index=first_index, state=state, out=self.out[:n], records=recs, local_states=self.local[:n])
-        return self.local[:n], self.out[:n]
+            self.pipe.run(frames, first_index=first_index, out=out[:n], records=recs)
+            return None, out[:n]
+        local = self.local[slot % self.slots]
+        state = None
+        if not clip_start:                                      # zero incoming state, blend from the first frame on
+            state = self.state
+            state.copy_(self.zero)
+        self.pipe.run(frames, first_index=first_index, state=state, out=out[:n], records=recs, local_states=local[:n])
+        return local[:n], out[:n]
 
     def sequential_scan(self, frames, first_index, state):
         """world 1: the chunk continues from the true state of the previous one (None at the start of the clip)."""

@@ -68,40 +68,187 @@ def settle_frames(p: float, eps: float = 2.0 ** -24) -> int:
     return int(math.ceil(math.log(eps) / math.log(p)))
 
 
+def choose_chunk(p: float, state_frame_bytes: int, default: int, mem_budget_bytes: int = 64 << 30, slots: int = 2) -> int:
+    """Frames per chunk for a sharded render with persistence p: at least settle_frames(p), so that every round is ONE
+    parallel hop instead of the world-1 hop chain (p = 0.5 -> 24, p = 0.95 -> 325), as long as the per-frame local
+    states of `slots` chunks (double buffering) fit the memory budget — 288 GB of HBM per GPU is what makes this the
+    default rather than a special case (1080p: 24.9 MB per state frame, 4K: 99.5 MB)."""
+    if p <= 0.0:
+        return int(default)
+    want = max(int(default), settle_frames(p))
+    cap = max(1, int(mem_budget_bytes // max(1, slots * state_frame_bytes)))
+    return min(want, cap) if cap < want else want
+
+
 class ShardedRender:
     """The per-round protocol.  `engine` provides
 
-        local_scan(frames, first_index, clip_start) -> (local_states float32 (n,H,W,3), out uint8 (n,H,W,3))
+        local_scan(frames, first_index, clip_start[, slot]) -> (local_states float32 (n,H,W,3), out uint8 (n,H,W,3))
             scan of the chunk from a zero incoming state (clip_start: the very first frame of the
-            clip passes through unblended, ref:1094-1095, and there is no carry at all)
+            clip passes through unblended, ref:1094-1095, and there is no carry at all); `slot` (0/1) names the
+            buffer pair to use when the engine double-buffers (engine.slots == 2)
         correct(local_states, carry, p, out) -> None
             out[j] = quantise(clip(local_states[j] + p^(j+1) * carry))
 
     `dist` is torch.distributed (or None for world 1).  When p^B is below float32 epsilon the
     chunk-final LOCAL state already equals the true one to rounding, so every rank forwards it
     at once (one parallel hop per round); otherwise the true finals are forwarded down the ring
-    rank by rank (exact for any B, at the cost of a world-1 hop chain)."""
+    rank by rank (exact for any B, at the cost of a world-1 hop chain).
 
-    def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None):
+    overlap=True (parallel-hop rounds only): `submit_round` enqueues round r's local scan and starts its hop, then
+    finishes round r-1 (waits for ITS hop — long done — and runs its fix-up), so the state frame travels while the
+    next round's scan runs; results come back one call late, `flush()` returns the last."""
+
+    def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None, overlap: bool = False, timing: bool = False):
         self.shard, self.p, self.engine, self.dist, self.group = shard, float(persistence), engine, dist, group
         self.carry_next_round: Optional[torch.Tensor] = None      # rank 0: true final of the previous round's last chunk
         self.parallel_hop = self.p > 0.0 and (self.p ** shard.chunk) < 2.0 ** -24
+        self.overlap = bool(overlap) and self.parallel_hop and shard.world > 1
+        self.timing = bool(timing)
+        self._pending = None          # overlapped mode: the round whose hop is in flight
+        self._marks = []              # timing: per finished round (scan events, hop-wait events + host seconds, fix-up events)
 
-    def _send_recv(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
-        ops, recv = [], None
-        d = self.dist
+    # ---- point-to-point plumbing --------------------------------------------------------------------------------
+    def _staged(self, like: torch.Tensor) -> bool:
         # RCCL moves device tensors directly (one xGMI hop).  gloo has no device point-to-point: stage through the
         # host (CPU tests, and rehearsals of several ranks on one GPU).
-        stage = recv_like.is_cuda and d.get_backend(self.group) == "gloo"
+        return like.is_cuda and self.dist.get_backend(self.group) == "gloo"
+
+    def _post(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
+        """Start the exchange; returns (works, recv buffer or None, staged)."""
+        ops, recv = [], None
+        d = self.dist
+        stage = self._staged(recv_like)
         if dst is not None and send is not None:
             ops.append(d.P2POp(d.isend, send.cpu() if stage else send.contiguous(), dst, self.group))
         if src is not None:
             recv = torch.empty_like(recv_like, device="cpu") if stage else torch.empty_like(recv_like)
             ops.append(d.P2POp(d.irecv, recv, src, self.group))
-        if ops:
-            for r in d.batch_isend_irecv(ops):
-                r.wait()
-        return recv.to(recv_like.device) if (stage and recv is not None) else recv
+        works = d.batch_isend_irecv(ops) if ops else []
+        return works, recv, stage
+
+    @staticmethod
+    def _complete(works, recv, stage, device):
+        for r in works:
+            r.wait()            # RCCL: orders the current stream behind the transfer (no host block); gloo: host wait
+        return recv.to(device) if (stage and recv is not None) else recv
+
+    def _send_recv(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
+        works, recv, stage = self._post(send, recv_like, src, dst)
+        return self._complete(works, recv, stage, recv_like.device)
+
+    # ---- timing (schedule_report) ---------------------------------------------------------------------------------
+    def _ev(self, like: Optional[torch.Tensor]):
+        if not self.timing or like is None or not like.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def schedule_report(self):
+        """Mean per-round split of the sharded-persistence schedule on this rank: local scan, stall of the compute
+        stream on the hop, fix-up pass (GPU microseconds from events on the compute stream), and the host seconds
+        spent waiting on the hop."""
+        if not self._marks:
+            return None
+        torch.cuda.synchronize()
+        scan = hop = fix = host = 0.0
+        n = 0
+        for m in self._marks:
+            if m["scan"][0] is None:
+                continue
+            scan += m["scan"][0].elapsed_time(m["scan"][1]) * 1e3
+            hop += m["hop"][0].elapsed_time(m["hop"][1]) * 1e3 if m["hop"][0] is not None else 0.0
+            fix += m["fix"][0].elapsed_time(m["fix"][1]) * 1e3 if m["fix"][0] is not None else 0.0
+            host += m["hop_host_s"]
+            n += 1
+        if not n:
+            return None
+        tot = scan + hop + fix
+        return {"rounds": n, "chunk": self.shard.chunk, "overlap": self.overlap, "parallel_hop": self.parallel_hop,
+                "scan_us": round(scan / n, 1), "hop_stall_us": round(hop / n, 1), "fixup_us": round(fix / n, 1),
+                "hop_host_wait_us": round(host / n * 1e6, 1),
+                "hop_plus_fixup_share": round((hop + fix) / tot, 4) if tot > 0 else None,
+                "fixup_frames": min(self.shard.chunk, settle_frames(self.p, 2.0 ** -26))}
+
+    # ---- overlapped schedule ---------------------------------------------------------------------------------------
+    def submit_round(self, frames: Optional[torch.Tensor], round_index: int, active: Optional[int] = None):
+        """Overlapped form of run_round: returns the list of (round_index, out) that became final in this call
+        (the previous round's, or this round's own when it needs no hop).  Falls back to run_round when the schedule
+        cannot overlap (world 1, p = 0, exact ring chain)."""
+        if not self.overlap:
+            out = self.run_round(frames, round_index, active)
+            return [(round_index, out)] if out is not None else []
+        sh, p = self.shard, self.p
+        w, r = sh.world, sh.rank
+        a = w if active is None else int(active)
+        if not (1 <= a <= w):
+            raise ValueError(f"active = {a} outside 1..{w}")
+        has_frames = frames is not None and frames.shape[0] > 0 and r < a
+        done = []
+        if not has_frames:
+            done += self.flush()
+            return done
+        c = sh.chunk_of(round_index)
+        first = c * sh.chunk
+        slot = round_index & 1
+        e0 = self._ev(frames)
+        if getattr(self.engine, "slots", 1) >= 2:
+            local, out = self.engine.local_scan(frames, first, clip_start=(c == 0), slot=slot)
+        else:
+            local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
+        e1 = self._ev(frames)
+        n = frames.shape[0]
+        final_local = local[n - 1]
+        full = a == w
+        dst = (r + 1) % w if (full or r + 1 < a) else None
+        src = (r - 1) % w if (full or r > 0) else None
+        rec = {"round": round_index, "c": c, "n": n, "local": local, "out": out, "full": full, "final": final_local,
+               "src": src, "dst": dst, "scan": (e0, e1), "posted": None}
+        if not self._staged(final_local):
+            # RCCL: the transfer is enqueued behind the scan now and runs beside whatever the compute stream does next
+            rec["posted"] = self._post(final_local if dst is not None else None, final_local, src, dst)
+        prev, self._pending = self._pending, rec
+        if prev is not None:
+            done.append(self._finish(prev))
+        return done
+
+    def _finish(self, rec):
+        p, r = self.p, self.shard.rank
+        final_local = rec["final"]
+        t0 = None
+        h0 = self._ev(final_local)
+        import time as _time
+        t0 = _time.perf_counter()
+        if rec["posted"] is None:      # gloo staging: posted here, AFTER the next round's scan was enqueued
+            rec["posted"] = self._post(final_local if rec["dst"] is not None else None, final_local, rec["src"], rec["dst"])
+        got = self._complete(*rec["posted"], final_local.device)
+        host_s = _time.perf_counter() - t0
+        h1 = self._ev(final_local)
+        if r == 0:
+            carry = self.carry_next_round
+            if rec["full"]:
+                self.carry_next_round = got      # what arrived now seeds the next round
+        else:
+            carry = got
+        if rec["c"] == 0:
+            carry = None
+        f0 = f1 = None
+        if carry is not None:
+            k = min(rec["n"], settle_frames(p, 2.0 ** -26))
+            f0 = self._ev(final_local)
+            self.engine.correct(rec["local"][:k], carry, p, rec["out"][:k])
+            f1 = self._ev(final_local)
+        if self.timing:
+            self._marks.append({"scan": rec["scan"], "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s})
+        return rec["round"], rec["out"]
+
+    def flush(self):
+        """Finish the round still in flight (overlapped mode); [] otherwise."""
+        if self._pending is None:
+            return []
+        rec, self._pending = self._pending, None
+        return [self._finish(rec)]
 
     def run_round(self, frames: Optional[torch.Tensor], round_index: int, active: Optional[int] = None):
         """frames: this rank's chunk for this round (None when it owns none).  `active` = how many ranks own a chunk in
@@ -113,6 +260,8 @@ class ShardedRender:
         a = w if active is None else int(active)
         if not (1 <= a <= w):
             raise ValueError(f"active = {a} outside 1..{w}")
+        if self.overlap:
+            raise RuntimeError("overlap=True: use submit_round()/flush() (results arrive one call late)")
         has_frames = frames is not None and frames.shape[0] > 0 and r < a
         c = sh.chunk_of(round_index)
         first = c * sh.chunk
@@ -125,13 +274,18 @@ class ShardedRender:
             # a partial last round: nothing to render here, and nobody downstream waits for this rank's state
             # (the exchange below is only between ranks < active, and there is no next round to seed)
             return None
+        e0 = self._ev(frames)
         local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
+        e1 = self._ev(frames)
         if p <= 0.0:
             return out
         n = frames.shape[0]
         final_local = local[n - 1]
         full = a == w                       # a full round also seeds rank 0 for the next round
         carry = None
+        import time as _time
+        h0 = self._ev(final_local)
+        t0 = _time.perf_counter()
         if w == 1:
             carry = self.carry_next_round
             true_final = final_local if carry is None else final_local + (p ** n) * carry
@@ -164,10 +318,17 @@ class ShardedRender:
                 true_final = final_local + (p ** n) * carry
                 if full or r + 1 < a:
                     self._send_recv(true_final, final_local, None, (r + 1) % w)
+        host_s = _time.perf_counter() - t0
+        h1 = self._ev(final_local)
+        f0 = f1 = None
         if carry is not None:
             # p^(j+1) * carry is below float32 resolution of the state scale after settle_frames(p) frames: the frames
             # behind that point keep the bytes of the local scan (a 1-LSB flip there needs the local value within
             # 2^-26 * 255 of a rounding boundary)
             k = min(n, settle_frames(p, 2.0 ** -26))
+            f0 = self._ev(final_local)
             self.engine.correct(local[:k], carry, p, out[:k])
+            f1 = self._ev(final_local)
+        if self.timing:
+            self._marks.append({"scan": (e0, e1), "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s})
         return out

@@ -172,3 +172,28 @@ def test_c_abi_consumer(pc, tmp_path):
     pipe = FramePipeline(torch.device("cuda", 0), h, w, rs, fps=30.0, noise_seed=0)
     exp, _ = pipe.run(torch.from_numpy(frames).cuda())
     assert np.array_equal(got, exp.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,batch", [(2, 8), (4, 26)])
+def test_bench_launches_its_own_ranks(config, batch):
+    """`python bench.py --gpus 2` as the driver calls it (no torch.distributed.run around it): the parent starts the two
+    ranks as child processes and relays rank 0's JSON line.  Both ranks share the test box's one GPU (gloo rehearsal);
+    config 4 exercises the overlapped sharded-persistence schedule (chunk 26 >= settle_frames(0.5) = 24)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, CRTFX_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(config),
+           "--batch", str(batch), "--cpu-frames", "0", "--repeats", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["dist"]["world_size_seen"] == 2 and len(res["dist"]["per_rank_frames_per_s"]) == 2
+    assert res["value"] > 0 and res["config"]["frames_per_step_per_gpu"] == batch
+    if config == 4:
+        sr = res["shard_schedule"]
+        assert sr["overlap"] and sr["parallel_hop"] and sr["rounds"] >= 2 and sr["fixup_frames"] == 26

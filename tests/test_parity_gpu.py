@@ -361,19 +361,16 @@ def test_1080p_frame_against_oracle(pc):
 
 
 def test_kernel_variants_agree(pc, monkeypatch):
-    """The three k_phosphor builds of one launch — gate-folded register-window kernel, its
-    runtime-flag instantiation, and the generic LDS-ring kernel — give identical bits."""
+    """The four k_phosphor builds of one launch — the column-owner kernel k_phosphor_cc, the gate-folded
+    register-window kernel, its runtime-flag instantiation, and the generic LDS-ring kernel — give identical bits."""
     from pythoncrt_amd import effects
     h, w = 150, 200
     frame = make_frame(h, w, seed=60, kind="grad")
     tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
     outs = {}
-    for name, env in (("folded", {}), ("runtime_flags", {"CRTFX_FORCE_RUNTIME_FLAGS": "1"}), ("generic", {"CRTFX_FORCE_GENERIC": "1"})):
-        for k in ("CRTFX_FORCE_RUNTIME_FLAGS", "CRTFX_FORCE_GENERIC"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        effects._tls.engines = {}          # the switches are read when a ctx is created
+    for name, opts in (("folded", {}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1})):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+        effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
         for sigma in (3.0, 1.2, 2.0, 5.0, 10.0):
             a = (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 2.0, 1.25, False, 1, 0, 0.0)
@@ -395,7 +392,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(st.cpu().numpy())
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("runtime_flags", "generic"):
+    for name in ("no_cc", "runtime_flags", "generic"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
 
@@ -602,7 +599,7 @@ def test_grouped_batch_equals_frame_by_frame(pc, persistence, monkeypatch):
     exactly as when each is rendered by its own call, and in order under the persistence IIR."""
     from pythoncrt_amd import effects
     from pythoncrt_amd.pipeline import FramePipeline, baseline_config
-    monkeypatch.setenv("CRTFX_GROUP", "4")
+    monkeypatch.setattr(effects, "DEBUG_OPTIONS", {"GROUP": 4})
     effects._tls.engines = {}
     dev = torch.device("cuda", torch.cuda.current_device())
     rs, _, _ = baseline_config(2)

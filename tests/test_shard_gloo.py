@@ -69,6 +69,55 @@ def worker(rank, world, port, p, chunk, rounds, outdir):
     dist.destroy_process_group()
 
 
+def overlap_worker(rank, world, port, p, chunk, n_frames, outdir):
+    """The overlapped schedule: submit_round returns the PREVIOUS round's frames, flush() the last."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = clip_frames(n_frames)
+    shard = FrameShard(world, rank, chunk)
+    render = ShardedRender(shard, p, OracleEngine(p), dist=dist, overlap=True)
+    assert render.overlap == ((p ** chunk) < 2.0 ** -24 and p > 0.0)
+    seen = []
+
+    def keep(done):
+        for r, out in done:
+            lo, _ = shard.frame_range(r, n_frames)
+            seen.append(r)
+            np.save(os.path.join(outdir, f"out_{lo}.npy"), out.numpy())
+
+    for r in range(shard.rounds(n_frames)):
+        lo, hi = shard.frame_range(r, n_frames)
+        mine = torch.from_numpy(np.stack(frames[lo:hi])) if hi > lo else None
+        done = render.submit_round(mine, r, active=shard.active_ranks(r, n_frames))
+        if render.overlap and mine is not None:
+            assert all(rr < r for rr, _ in done)          # results arrive one call late
+        keep(done)
+    keep(render.flush())
+    assert seen == sorted(seen) and len(seen) == len(shard.my_chunks(n_frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("p,chunk,n_frames", [(0.5, 26, 26 * 2 * 3), (0.5, 26, 26 * 5 + 7), (0.3, 16, 16 * 2 * 2 + 16), (0.9, 5, 25), (0.0, 4, 16)])
+def test_two_rank_overlapped_schedule(tmp_path, p, chunk, n_frames):
+    """ShardedRender(overlap=True): round r's hop is in flight while round r+1 is scanned; the fix-up of round r runs
+    one call later.  Same frames as the in-order render; schedules that cannot overlap (p = 0, exact ring chain) fall
+    back to the synchronous protocol behind the same calls."""
+    world = 2
+    mp.spawn(overlap_worker, args=(world, free_port(), p, chunk, n_frames, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out_{lo}.npy") for lo in range(0, n_frames, chunk)])
+    frames = clip_frames(n_frames)
+    state, exp = None, []
+    for i, f in enumerate(frames):
+        state, u8 = orc.persistence_blend(state, static_of(f, i), p)
+        exp.append(u8)
+    exp = np.stack(exp)
+    assert got.shape == exp.shape
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -142,3 +191,6 @@ def test_shard_plan():
     assert covered == list(range(300))
     assert settle_frames(0.5) == 24 and settle_frames(0.95) == 325 and settle_frames(0.0) == 0
     assert ShardedRender(FrameShard(2, 0, 26), 0.5, None).parallel_hop and not ShardedRender(FrameShard(2, 0, 3), 0.5, None).parallel_hop
+    from pythoncrt_amd.shard import choose_chunk
+    assert choose_chunk(0.5, 1920 * 1080 * 12, 128) == 128 and choose_chunk(0.95, 1920 * 1080 * 12, 128) == 325 and choose_chunk(0.0, 1, 32) == 32
+    assert choose_chunk(0.95, 1 << 30, 16, mem_budget_bytes=64 << 30) == 32       # capped by memory: 2 slots x 32 x 1 GiB

@@ -2,7 +2,7 @@
 """Dev tool (GPU box): per-phase cycle shares of k_phosphor_rr from a CRTFX_STAMP diagnostic build.
 
     hipcc ... -DCRTFX_STAMP -o build/ab/lib_stamp.so pythoncrt_amd/csrc/crtfx.hip
-    python tools/phase_profile.py [config]
+    python tools/phase_profile.py [config] [NO_CC=1 ...]
 
 Slots: 0 A(grade->LDS) 1 barrier 2 B(H-pass) 3 barrier 4 C1(V-pass) 5 barrier 6 C2(masks+store)."""
 import os, sys
@@ -14,10 +14,14 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda", 0)
 n_words = 4096 * 4 * 8
 dbg = torch.zeros(n_words, dtype=torch.int64, device=dev)
-os.environ["CRTFX_DBG_PTR"] = hex(dbg.data_ptr())
+from pythoncrt_amd import _lib, effects
 from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+for o in sys.argv[2:]:
+    k, v = o.split("=")
+    effects.DEBUG_OPTIONS[k.upper()] = int(v)
 rs, h, w = baseline_config(cfg)
 pipe = FramePipeline(dev, h, w, rs, noise_seed=1)
+_lib.check(pipe.lib, pipe.engine.ctx, pipe.lib.crtfx_debug_buffer(pipe.engine.ctx, dbg.data_ptr()))
 frames = torch.randint(0, 256, (2, h, w, 3), dtype=torch.uint8, device=dev)
 pipe.run(frames)
 torch.cuda.synchronize()
@@ -26,7 +30,7 @@ pipe.run(frames[:1])
 torch.cuda.synchronize()
 d = dbg.cpu().view(-1, 8).double()
 d = d[d.sum(1) > 0]
-names = ["A grade->LDS", "barrier A|C2", "B H-pass", "barrier B|C1", "C1 V-pass", "-", "C2 masks+store", "-"]
+names = ["A grade->LDS", "barrier A|C2", "B H-pass", "barrier B|C1", "C1 V-pass / G", "-", "C2 masks+store", "-"]
 tot = d.sum(1)
 print(f"waves {len(d)}  mean cycles/wave {tot.mean():.0f}  min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names[:7]):
