@@ -219,6 +219,7 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   FORCE_GENERIC        always take the general-purpose kernels (the LDS-ring k_phosphor, k_point, k_warp)
  *   FORCE_RUNTIME_FLAGS  never take a gate-folded instantiation
  *   NO_CC                full-chain launches that park a pre-warp image stay on k_phosphor_rr (A/B against k_phosphor_cc)
+ *   FORCE_CC             ... take k_phosphor_cc for every radius and both pixel formats (it is the default only where it is faster)
  *   GROUP, SEG_ROWS      frames per grid (1..4) / rows per block of the register-window kernels; 0 = the planner's choice
  *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4)
  *   POINT_TILES          rows per k_point block (1..16; 0 = default)
@@ -226,7 +227,7 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   DEBUG_PLAN           print the planned launch shape to stderr */
 typedef enum crtfx_option {
     CRTFX_OPT_FORCE_GENERIC = 1, CRTFX_OPT_FORCE_RUNTIME_FLAGS = 2, CRTFX_OPT_NO_CC = 3, CRTFX_OPT_GROUP = 4, CRTFX_OPT_SEG_ROWS = 5,
-    CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9
+    CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9, CRTFX_OPT_FORCE_CC = 10
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 

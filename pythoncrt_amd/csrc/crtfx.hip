@@ -32,7 +32,7 @@ struct crtfx_ctx {
     int pix_fmt = CRTFX_PIX_U8;
     bool params_set = false;
     KParams kp{};
-    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts, trash;
+    DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
@@ -50,6 +50,7 @@ struct crtfx_ctx {
     int warp_rows = 2;               // CRTFX_OPT_WARP_ROWS = 1|2|4: output rows per k_warp_lean thread
     int point_tiles = 0;             // CRTFX_OPT_POINT_TILES = n: rows (wavefronts) per k_point block, 1..16 (0 = default)
     bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
+    bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
     bool debug_plan = false;
@@ -179,7 +180,7 @@ size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bo
 // blocks 29 us against 34 us at 64 rows — filling the slots beats the extra halo rows; floor 24 rows.
 int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
     const int strips = (W + TW - 1) / TW;
-    const size_t lds = phosphor_rr_lds_bytes(R >= 1 && R <= RR_MAX_RADIUS ? R : 9, 128, false, pix);
+    const size_t lds = phosphor_rr_lds_bytes(rr_build_radius(R) ? R : 9, 128, false, pix);
     int bpc = (int)(163840 / lds);
     if (bpc > 4) bpc = 4;      // 4 waves per SIMD is what the register budget allows
     if (bpc < 1) bpc = 1;
@@ -202,7 +203,7 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
 struct GridPlan { int g, seg; };
 GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed, bool cc = false) {
     const int strips = (W + TW - 1) / TW;
-    const int Rk = R >= 1 && R <= RR_MAX_RADIUS ? R : 9;
+    const int Rk = rr_build_radius(R) ? R : 9;
     const size_t lds = cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
     int bpc = (int)(163840 / lds);
     const int by_regs = cc ? cc_min_waves(Rk) : rr_min_waves(Rk, folded);      // a block = one wave per SIMD
@@ -261,28 +262,41 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
     // (text overlays before the effects, or after them when the same kernel also commits) are handled by the runtime-gate build only
     const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) || kf.overlay_before || ko.overlay_after;
     (void)folded; (void)needs_runtime;      // both pixel formats have a gate-folded and a runtime-gate build
-    return !c->force_generic && R >= 1 && R <= RR_MAX_RADIUS && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
+    return !c->force_generic && rr_build_radius(R) == R && R >= 1 && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
            ko.blend == CRTFX_BLEND_NONE;
+}
+
+constexpr int CC_MIN_RADIUS = 7;
+bool use_cc(const crtfx_ctx* c, int R) {
+    return c->pix_fmt == CRTFX_PIX_U8 && (c->force_cc || R >= CC_MIN_RADIUS) && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
 void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
-#define CRTFX_RR_ENTRY(r) , rr_launch_##r
-    static const rr_launch_fn table[RR_MAX_RADIUS + 1] = {nullptr CRTFX_RR_RADII(CRTFX_RR_ENTRY)};
+    static rr_launch_fn table[MAX_RADIUS + 1] = {};
+    static const bool table_ready = [] {
+#define CRTFX_RR_ENTRY(r) table[r] = rr_launch_##r;
+        CRTFX_RR_RADII(CRTFX_RR_ENTRY)
 #undef CRTFX_RR_ENTRY
-    const int R = c->kp.R;
+        return true;
+    }();
+    (void)table_ready;
+    const int R = c->kp.R;          // the BUILD radius (crtfx_set_params pads the taps of a bucketed radius)
     bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
     if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
     for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     // the column-owner kernel takes the full-chain launches that park a pre-warp image (warp and / or persistence behind them)
-    bool cc = folded && !c->no_cc;
+    // — for uint8 frames and radii >= CC_MIN_RADIUS, where it is the faster build (4K, R = 9: 135 vs 140 us per 2-frame launch;
+    // 1080p, R = 4: 65 vs 61.5; 8K half frames: 288 vs 284: profiles/r02_cc_ab.txt).  Its stores address a frame's scratch
+    // image with 32-bit byte offsets.
+    bool cc = folded && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
     int& seg_slot = c->seg_for[cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, cc).seg;   // planned once per (kernel build, group size)
     const int seg = seg_slot;
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const int variant = cc ? (c->pix_fmt == CRTFX_PIX_F16 ? 5 : 4) : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0));
+    const int variant = cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0));
     const bool runtime = !folded;
     const size_t lds = cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
                           : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
@@ -379,6 +393,8 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     if (two) { k1 = KOut{}; k1.pre = c->pre; }
     k1.dbg = c->dbg;
     if (gauss) {
+        if (!lean_ok(c, kf, k1) && c->kp.R > GENERIC_MAX_RADIUS)
+            return fail(c, CRTFX_E_UNSUPPORTED, "injected per-pixel planes / an in-kernel blend go through the LDS-ring kernel, which stops at bloom radius %d (asked: a build radius of %d)", GENERIC_MAX_RADIUS, c->kp.R);
         launch_phosphor(c, kf, k1, s);
     } else {
         if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
@@ -468,7 +484,7 @@ int crtfx_destroy(crtfx_ctx* c) {
     if (!c) return CRTFX_OK;
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->trash, &c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
+    for (DevBuf* b : {&c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
                       &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
@@ -491,7 +507,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         if ((p->fbd_xofs != nullptr) != (p->fbd_yofs != nullptr) || (p->fbd_xofs && !(p->fbd_xw && p->fbd_yw))) return fail(c, CRTFX_E_INVALID, "fbd_* axes must be given together");
     } else if (fl & CRTFX_F_BLOOM) {
         if (p->bloom_radius < 0 || p->bloom_radius > MAX_RADIUS)
-            return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d outside [0,%d] (sigma up to ~21)", p->bloom_radius, MAX_RADIUS);
+            return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d outside [0,%d] (sigma up to ~42.8)", p->bloom_radius, MAX_RADIUS);
+        if (c->force_generic && p->bloom_radius > GENERIC_MAX_RADIUS)
+            return fail(c, CRTFX_E_UNSUPPORTED, "the LDS-ring kernel stops at bloom radius %d", GENERIC_MAX_RADIUS);
         if (!p->bloom_taps) return fail(c, CRTFX_E_INVALID, "bloom on but bloom_taps NULL");
     }
     if ((fl & CRTFX_F_TRIAD) && !p->triad_row && !p->triad_full_dev) return fail(c, CRTFX_E_INVALID, "triad on but no mask");
@@ -503,7 +521,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
 
     int rc;
     const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
-    const int R = ((fl & CRTFX_F_BLOOM) && !fastb) ? p->bloom_radius : 0;
+    const int R_asked = ((fl & CRTFX_F_BLOOM) && !fastb) ? p->bloom_radius : 0;
+    // radii beyond the per-radius builds run the next bucket's build on zero-padded taps (crtfx_internal.h); injected
+    // per-pixel planes / FORCE_GENERIC take the LDS-ring kernel at the radius asked for (<= GENERIC_MAX_RADIUS)
+    const bool ring_only = c->force_generic || p->triad_full_dev || p->vignette_full_dev;
+    const int R = (R_asked > RR_MAX_RADIUS && !(ring_only && R_asked <= GENERIC_MAX_RADIUS)) ? rr_build_radius(R_asked) : R_asked;
     const bool grain_up = (fl & CRTFX_F_NOISE) && p->grain_size > 1;
     if (grain_up && !(p->grain_xofs && p->grain_xw && p->grain_yofs && p->grain_yw && p->grain_w >= 1 && p->grain_h >= 1))
         return fail(c, CRTFX_E_INVALID, "grain_size > 1 needs the grain_* resize axes");
@@ -546,7 +568,10 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
     k.noise_scale = p->noise_scale; k.warp_k = p->warp_k; k.cx = p->warp_cx; k.cy = p->warp_cy;
     k.vig_strength = p->vignette_strength;
-    if ((fl & CRTFX_F_BLOOM) && !fastb) std::memcpy(k.taps, p->bloom_taps, (2 * R + 1) * sizeof(float));
+    if ((fl & CRTFX_F_BLOOM) && !fastb) {
+        std::memset(k.taps, 0, sizeof k.taps);
+        std::memcpy(k.taps + (R - R_asked), p->bloom_taps, (2 * R_asked + 1) * sizeof(float));      // centred in the build's 2R + 1 taps
+    }
     k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
@@ -556,11 +581,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         if ((rc = upload(c, c->consts, cst, sizeof(cst)))) return rc;
         k.consts = (const float*)c->consts.p;
     }
-    if (!c->trash.p) {      // where k_phosphor_cc's branch-free stores of rows / lanes outside the frame land; never read
-        HIP_TRY(c, hipMalloc(&c->trash.p, (size_t)CC_TRASH_WAVES * 64 * sizeof(float)));
-        c->trash.bytes = (size_t)CC_TRASH_WAVES * 64 * sizeof(float);
-    }
-    k.trash = (float*)c->trash.p;
+
     k.vig_nx2 = (const double*)c->nx2.p; k.vig_ny2 = (const double*)c->ny2.p;
     k.vig_full = p->vignette_full_dev;
     k.xhat = (const float*)c->xhat.p; k.yhat = (const float*)c->yhat.p;
@@ -585,7 +606,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
         const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
-        const bool cc_plan = folded_plan && !c->no_cc && (k.flags & CRTFX_F_WARP);
+        const bool cc_plan = folded_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_plan);
         if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) { gp.g = c->opt_group; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, gp.g); }
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;
@@ -603,7 +624,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         c->seg_for[cc_plan ? 2 : (folded_plan ? 1 : 0)][gp.g] = gp.seg;
     }
 
-    if (fl & CRTFX_F_BLOOM) {
+    if ((fl & CRTFX_F_BLOOM) && R <= GENERIC_MAX_RADIUS) {
         const size_t lds = phosphor_lds_bytes(R);
         if (lds > 160 * 1024) return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d needs %zu B of LDS", R, lds);
         // opt in to > 64 KiB of dynamic LDS
@@ -866,6 +887,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_FORCE_GENERIC: c->force_generic = value != 0; break;
     case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
+    case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
     case CRTFX_OPT_GROUP: if (value < 0 || value > MAX_GROUP) return fail(c, CRTFX_E_INVALID, "group %d outside 0..%d", value, MAX_GROUP); c->opt_group = value; break;
     case CRTFX_OPT_SEG_ROWS: if (value < 0) return fail(c, CRTFX_E_INVALID, "seg_rows %d < 0", value); c->opt_seg_rows = value ? ((value + NB - 1) / NB) * NB : 0; break;
     case CRTFX_OPT_WARP_ROWS: if (value != 1 && value != 2 && value != 4) return fail(c, CRTFX_E_INVALID, "warp rows must be 1, 2 or 4"); c->warp_rows = value; break;

@@ -22,7 +22,8 @@
 
 namespace crtfx {
 
-constexpr int MAX_RADIUS = 64;            // bloom radius limit: ring of (NB + 2R) rows must fit LDS
+constexpr int MAX_RADIUS = 128;           // bloom radius limit (sigma <= 42.8): the largest register-window build; the LDS-ring kernel k_phosphor<-1> stops at GENERIC_MAX_RADIUS
+constexpr int GENERIC_MAX_RADIUS = 64;    // its ring of (NB + 2R) rows must fit LDS
 constexpr int MAX_TAPS = 2 * MAX_RADIUS + 1;
 
 // ---------------------------------------------------------------------------------------
@@ -64,9 +65,7 @@ struct KParams {
     int hw, hh;                                                         // half-res size (max(1, W//2), max(1, H//2))
     float* ds;                                                          // half-res thresholded source, hh x hw x 3 float32 (ctx scratch)
     const float* consts;                                                // ctx-owned: float 1,1,1,1 then 112 zero bytes — a valid address for loads a disabled stage would make (k_point_sel)
-    float* trash;                                                       // ctx-owned, CC_TRASH_WAVES x 64 floats, never read: where k_phosphor_cc's branch-free stores of rows / lanes outside the frame go
 };
-constexpr int CC_TRASH_WAVES = 1024;
 
 struct KFrame {
     const uint8_t* __restrict__ in;
@@ -466,11 +465,7 @@ __device__ __forceinline__ void emit_pixel(const KParams& P, const KFrame& F, co
         double v0 = 0, v1 = 0, v2 = 0;
         if (LEAN || live) tail_masks<double, !LEAN>(P, F, y, x, M, r, g, b, lut_g, lut_inv, v0, v1, v2);   // lean callers pass valid (replicated) pixels in dead lanes: no branch
         if (O.pre) {
-#ifdef CC_EXP_NOSTORE
-            if (v0 == -12345.0) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
-#else
             if (live) { float* p = O.pre + pix * 3u; p[0] = (float)v0; p[1] = (float)v1; p[2] = (float)v2; }
-#endif
             return;
         }
         if (live) packed = commit_pixel<double, COMMIT>(O, pix, v0, v1, v2);
@@ -961,8 +956,12 @@ constexpr uint32_t SF_FULL = SF_FULL_GATES;
 // PIX: pixel format of the frames (folded like the gates); half frames park 2 dwords per centre pixel.
 // Radii 13..30 (bloom sigma up to 10, the reference GUI's range): the register window (2R + 8 values) no longer
 // fits 128 VGPRs, so those builds run 3 (R <= 20) or 2 resident blocks per CU.
+#ifndef RR_BIG_WAVES_FROM
+#define RR_BIG_WAVES_FROM 49      // build radii from here on get the whole register file (one block per CU): measured at 4K, R = 48: 677 us with
+                                  // two blocks per CU (29 spilled VGPRs) vs 765 with one; R = 64: 1362 vs 1105 (profiles/r02_sigma_sweep.txt)
+#endif
 __host__ __device__ constexpr int rr_min_waves(int R, bool folded) {
-    return R <= 12 ? (folded ? 4 : CRTFX_RR_WAVES) : (R <= 20 ? (folded ? 3 : 2) : 2);
+    return R <= 12 ? (folded ? 4 : CRTFX_RR_WAVES) : (R <= 20 ? (folded ? 3 : 2) : (R < RR_BIG_WAVES_FROM ? 2 : 1));
 }
 template <int RT, uint32_t SF, int PIX = 0>
 __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) void k_phosphor_rr(KParams Pin, KGroup G, int seg_rows) {
@@ -1325,18 +1324,42 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
 //   two barriers per eight rows, as before.  The two roles run separate copies of the loop (same trip count, same
 //   barriers): no role test inside a phase.
 // ---------------------------------------------------------------------------------------
-__host__ __device__ constexpr int cc_sws(int R) { return (rr_swp(R) + 31) & ~31; }
-__host__ __device__ constexpr int cc_cring_words(int R, int pix) { return pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW; }
+// LDS access by BYTE OFFSET from the start of the workgroup's LDS (k_phosphor_cc has no static LDS, so its dynamic
+// block starts at 0 — checked once at kernel entry).  hipcc forms the address of lut[idx] as v_lshl_add_u32(idx, 2, 0):
+// a 3.4-cycle VOP3 where a 1.9-cycle v_lshlrev_b32 plus the instruction's immediate offset does (33 of them per trip).
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef __attribute__((address_space(3))) double lds_f64_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+#define LDS_AT(T, off) (*(T*)(uintptr_t)(uint32_t)(off))
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc.x += w.h * tp.lo', acc.y += w.h * tp.hi'  with ONE v_pk_fma_f32: h = low / high half of the VGPR pair w (broadcast to
+// both lanes of the packed op through op_sel), (lo', hi') = the SGPR pair tp as it is or swapped.  The separable blur's
+// 2 x (2R + 1) x 3 fused multiply-adds per pixel are 34 % of the kernel's VALU time (tools/isa_cost.py); one input
+// feeds two neighbouring outputs with two neighbouring taps, which is exactly this instruction: measured 3.4 cycles
+// against 2 x 2.4 for two v_fmac_f32 with an SGPR tap (profiles/r02_valu_cost.txt).  Each accumulator still receives
+// its taps in the oracle's order (left to right / top to bottom), each product fused: the same bits.
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 w, bool whigh, unsigned long long tp, bool swap) {
+    if (!whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else if (!whigh && swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else if (whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
+}
+
+// staging plane stride: >= the staged width and == 4 (mod 8) dwords, so that the two (row, channel) planes one 16-lane
+// ds_read_b128 group covers in the H pass (8 lanes each, 32 bytes apart) land on disjoint banks
+__host__ __device__ constexpr int cc_sws(int R) { return ((rr_swp(R) + 3) & ~7) + 4; }
+constexpr int CC_HROW = 3 * TW + 4;       // H-row tile row stride in floats: == 4 (mod 32), the H pass's column-strided stores stay 2-way
+__host__ __device__ constexpr int cc_cring_words(int R, int pix) { return pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW; }   // half: [CR][TW][3] uint16; uint8: [CR][TW] packed r | g<<8 | b<<16
 // LDS words: staging, ONE H-row tile, LUTs, centre ring, a1 table (uint8), vignette tile (f64), two grain tiles (f32), row table
 __host__ __device__ constexpr int cc_lds_words(int R, int pix) {
-    return NB * 3 * cc_sws(R) + NB * 3 * TW + 2 * LUT_STRIDE + cc_cring_words(R, pix) + (pix ? 0 : 256) + NB * TW * 2 + 2 * NB * TW + 16 * 4;
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + cc_cring_words(R, pix) + (pix ? 0 : 256) + NB * TW * 2 + 2 * NB * TW + 16 * 4;
 }
 __host__ __device__ constexpr int cc_min_waves(int R) { return R <= 12 ? 4 : (R <= 20 ? 3 : 2); }
 #ifndef CC_A3
 #define CC_A3(na) ((na) / 5)                // A-phase wave-items (64 staged pixels each) of the helper wave; waves 0-2 share the rest
-#endif
-#ifndef CC_B3
-#define CC_B3 1                             // B-phase wave-items (64 x 4 H-pass outputs each) of the helper wave, of 6; waves 0-2 share the rest
 #endif
 
 template <int RT, int PIX>
@@ -1357,20 +1380,28 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     constexpr int NA = (NB * SWP + 63) / 64;             // A-phase wave-items
     constexpr int A3 = CC_A3(NA);                        // ... of the helper wave (the last A3 items)
     constexpr int AO = (NA - A3 + 2) / 3;                // ... of each consumer wave (items wave, wave + 3, ...)
-    constexpr int NBI = NB * 48 / 64;                    // B-phase wave-items (6)
-    constexpr int B3 = CC_B3;
-    constexpr int BO = (NBI - B3 + 2) / 3;
-    constexpr int HT = NB * 3 * TW;
+    constexpr int HT = NB * CC_HROW;
     constexpr bool NLUT = PIX == 0;
-    float* stg = smem;                                   // [NB][3][SWS]
-    float* hrow = stg + NB * 3 * SWS;                    // [NB][TW][3]  interleaved like the image row
-    float* lut = hrow + HT;                              // [2][LUT_STRIDE]
-    uint32_t* cring = reinterpret_cast<uint32_t*>(lut + 2 * LUT_STRIDE);    // uint8: [CR][TW] packed r|g<<8|b<<16.  half: [CR][TW][3] uint16
-    uint16_t* cring16 = reinterpret_cast<uint16_t*>(cring);
-    float* nlut = reinterpret_cast<float*>(cring + cc_cring_words(R, PIX));           // [256] u / 255.0 (uint8 frames)
-    double* gvig = reinterpret_cast<double*>(nlut + (NLUT ? 256 : 0));               // [NB][TW]
-    float* gn = reinterpret_cast<float*>(gvig + NB * TW);                            // [2][NB][TW]
-    uint32_t* rowtab = reinterpret_cast<uint32_t*>(gn + 2 * NB * TW);                // [16][4]: scan gain bits, ny2 lo, ny2 hi, -
+    // LDS map, byte offsets from 0 (LDS_AT): every hot access is `constant + per-lane offset`, so that the constant rides in the
+    // instruction's immediate and the per-lane part is one shift or add
+    constexpr uint32_t STG_B = 0;                                            // [NB][3][SWS] float      staging tile
+    constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
+    constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   triad LUT pair
+    constexpr uint32_t CRING_B = LUT_B + 2 * LUT_STRIDE * 4;                 // uint8: [CR][TW] packed dwords; half: [CR][TW][3] uint16   parked centre samples
+    constexpr uint32_t NLUT_B = CRING_B + cc_cring_words(R, PIX) * 4;        // [256] float             u / 255.0 (uint8 frames)
+    constexpr uint32_t GVIG_B = NLUT_B + (NLUT ? 256 * 4 : 0);               // [NB][TW] double         vignette gain tile
+    constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
+    constexpr uint32_t ROWTAB_B = GN_B + 2 * NB * TW * 4;                    // [16][4] uint32          scan gain bits, ny2 lo, ny2 hi, -
+    static_assert(ROWTAB_B + 16 * 4 * 4 == (uint32_t)cc_lds_words(R, PIX) * 4, "LDS map and cc_lds_words disagree");
+    float* stg = smem;
+    float* hrow = smem + HROW_B / 4;
+    float* lut = smem + LUT_B / 4;
+    uint16_t* cring16 = reinterpret_cast<uint16_t*>(smem + CRING_B / 4);
+    float* nlut = smem + NLUT_B / 4;
+    double* gvig = reinterpret_cast<double*>(smem + GVIG_B / 4);
+    uint32_t* rowtab = reinterpret_cast<uint32_t*>(smem + ROWTAB_B / 4);
+    float* gn = smem + GN_B / 4;
+    if ((uint32_t)(uintptr_t)(lds_f32_t*)smem != 0u) __builtin_trap();      // LDS_AT assumes the dynamic block starts at 0
 
     const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     const int tid = (threadIdx.x + ((wg_lin & 3) << 6)) & (RR_THREADS - 1);          // roles rotate over the SIMDs with the dispatch number
@@ -1386,6 +1417,15 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     if constexpr (NLUT) { if (tid < 256) nlut[tid] = norm_u8((uint32_t)tid); }
     const float* taps = P.taps;
 #define TAP(k) taps[(k) <= R ? (k) : 2 * R - (k)]
+    // the taps as R + 1 aligned SGPR pairs (tap[2m], tap[2m+1]); the pair (tap[t], tap[t-1]) a packed FMA wants is pair
+    // (t-1)/2 swapped when t is odd and, the kernel being symmetric (tap[k] == tap[2R-k] bit for bit), pair (2R-t)/2 as
+    // it stands when t is even
+    unsigned long long tp[R + 1];
+#pragma unroll
+    for (int m = 0; m <= R; ++m)
+        tp[m] = (unsigned long long)__float_as_uint(taps[2 * m]) | ((unsigned long long)(2 * m + 1 <= 2 * R ? __float_as_uint(taps[2 * m + 1]) : 0u) << 32);
+    // acc.x += w * tap[t], acc.y += w * tap[t-1]   (1 <= t <= 2R)
+#define PK_TAPS(acc, wpair, whigh, t) pk_fma_bcast(acc, wpair, whigh, ((t) & 1) ? tp[((t) - 1) / 2] : tp[(2 * R - (t)) / 2], ((t) & 1) != 0)
     const uint32_t row_elems = (uint32_t)W * 3u;
     const int n_iter = (y_end + R - (y_begin - R) + NB - 1) / NB;                    // loop trips (same for both roles)
 #ifdef CRTFX_STAMP
@@ -1409,42 +1449,59 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
         return load_raw(PIX, F.in, ro + o_r, ro + o_g, ro + o_b);
     };
-    auto a_stage = [&](int q, int crow0, RawRGB v) {
+    // a1 of one staged pixel (the table read / the arithmetic), then its stores: callers run the lookups of ALL their items before
+    // the first store, so that the LDS round trips overlap instead of queueing item after item
+    auto a_lookup = [&](RawRGB v, float (&o)[3]) {
+        if constexpr (NLUT) { o[0] = LDS_AT(lds_f32_t, NLUT_B + (v.r << 2)); o[1] = LDS_AT(lds_f32_t, NLUT_B + (v.g << 2)); o[2] = LDS_AT(lds_f32_t, NLUT_B + (v.b << 2)); }
+        else { o[0] = norm_px(PIX, v.r); o[1] = norm_px(PIX, v.g); o[2] = norm_px(PIX, v.b); }
+    };
+    auto a_write = [&](int q, int crow0, RawRGB v, const float (&o)[3]) {
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int j = it / SWP, i = it - j * SWP;
-        float r, g, b;
-        if constexpr (NLUT) { r = nlut[v.r]; g = nlut[v.g]; b = nlut[v.b]; }
-        else { r = norm_px(PIX, v.r); g = norm_px(PIX, v.g); b = norm_px(PIX, v.b); }
         if (i >= pad && i < pad + TW) {
             int cr = crow0 + j;
             cr = cr >= CR ? cr - CR : cr;
             if constexpr (PIX) { uint16_t* cp = cring16 + (cr * TW + (i - pad)) * 3; cp[0] = (uint16_t)v.r; cp[1] = (uint16_t)v.g; cp[2] = (uint16_t)v.b; }
-            else cring[cr * TW + (i - pad)] = v.r | (v.g << 8) | (v.b << 16);
+            else LDS_AT(lds_u32_t, CRING_B + (uint32_t)((cr * TW + (i - pad)) * 4)) = v.r | (v.g << 8) | (v.b << 16);
         }
         float* sp = stg + (j * 3) * SWS + i;
-        sp[0] = r; sp[SWS] = g; sp[2 * SWS] = b;
+        sp[0] = o[0]; sp[SWS] = o[1]; sp[2 * SWS] = o[2];
     };
-    auto b_item = [&](int q) {                                  // H pass of wave-item q: 64 lanes x 4 adjacent pixels of one channel and row
-        const int it = (q << 6) + lane;
-        const int j = it / 48, rem = it - j * 48;
-        const int c = rem >> 4, gq = rem & 15;
-        const lds_cv_f32x4* srow = (const lds_cv_f32x4*)smem4 + ((j * 3 + c) * (SWS / 4) + gq);
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // H pass of the staging tile by a consumer wave: NB x 3 (row, channel) planes, 8 lanes per plane, 8 adjacent outputs per
+    // lane.  Lane -> (plane, octet) goes through the hardware's 16-lane ds_read_b128 groups ({0-3,12-15,20-27},
+    // {4-11,16-19,28-31}, ... of each 32): a group reads two consecutive planes, which SWS == 4 (mod 8) keeps on disjoint
+    // banks.  Per output the taps run left to right, fused (the oracle's RowFilter order).
+    auto h_pass = [&](int w) {
+        const int l5 = lane & 31;
+        const int hg = ((lane >> 5) << 1) | ((l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28 ? 1 : 0);      // 16-lane group 0..3
+        const int pos = (hg & 1) ? (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16)) : (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12));   // 0..15 inside it
+        const int plane = 8 * w + 2 * hg + (pos >> 3);          // j * 3 + c
+        const int g8 = pos & 7;
+        const int j = plane / 3, c = plane - 3 * j;
+        const lds_cv_f32x4* srow = (const lds_cv_f32x4*)smem4 + (plane * (SWS / 4) + 2 * g8);
+        f32x2 acc2[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};      // outputs (0,1) (2,3) (4,5) (6,7)
         constexpr int off = pad - R;
+        constexpr int NQ = (2 * pad + 8) / 4;
+        f32x4 vq[NQ];
 #pragma unroll
-        for (int qq = 0; qq < (2 * pad + 4) / 4; ++qq) {
-            const f32x4 vv = srow[qq];
-            const float ve[4] = {vv[0], vv[1], vv[2], vv[3]};
+        for (int qq = 0; qq < NQ; ++qq) vq[qq] = srow[qq];       // all reads in flight before the first tap (the FMAs then wait quad by quad)
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+            const f32x4 vv = vq[qq];
+            const f32x2 vp[2] = {{vv[0], vv[1]}, {vv[2], vv[3]}};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int tt = 4 * qq + e - i - off;
-                    if (tt >= 0 && tt <= 2 * R) acc[i] = fmaf(ve[e], TAP(tt), acc[i]);
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int t = 4 * qq + e - 2 * pp - off;      // tap of the pair's first output; its second takes t - 1
+                    if (t == 0) acc2[pp].x = fmaf(vp[e >> 1][e & 1], taps[0], acc2[pp].x);
+                    else if (t >= 1 && t <= 2 * R) PK_TAPS(acc2[pp], vp[e >> 1], (e & 1) != 0, t);
+                    else if (t == 2 * R + 1) acc2[pp].y = fmaf(vp[e >> 1][e & 1], taps[0], acc2[pp].y);      // tap[2R] == tap[0]
                 }
         }
-        float* hp = hrow + (j * TW + 4 * gq) * 3 + c;          // interleaved tile: four floats 12 bytes apart (48 lanes, 48 banks)
-        hp[0] = acc[0]; hp[3] = acc[1]; hp[6] = acc[2]; hp[9] = acc[3];
+        float* hp = hrow + j * CC_HROW + 8 * g8 * 3 + c;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) { hp[6 * pp] = acc2[pp].x; hp[6 * pp + 3] = acc2[pp].y; }
     };
 
     if (wave < 3) {
@@ -1453,10 +1510,42 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         const int fcol = f / 3, fch = f - 3 * fcol;
         const bool fin = x0 + fcol < W;
         const float cm = P.triad_row[min(x0 + fcol, W - 1) * 3 + fch];           // a7 mask of this float
-        float* const trash = P.trash + (((uint32_t)wg_lin * 3u + (uint32_t)wave) & (CC_TRASH_WAVES - 1)) * 64 + lane;
-        float win[L];
+        const uint32_t cpl = (uint32_t)(fcol * 4 + fch);                         // this float's byte in a centre-ring row (packed pixel fcol, byte fch)
+        const uint32_t gcol8 = (uint32_t)fcol * 8u, gcol4 = (uint32_t)fcol * 4u;  // its pixel in the vignette / grain tiles
+        // The pre-warp image is written through a buffer resource (base, H * W * 12 bytes): one SGPR descriptor + a 32-bit
+        // byte offset per store, no 64-bit address arithmetic, and an offset past the image is DROPPED by the hardware's
+        // range check — so rows outside the segment (offset | all-ones, a scalar mask) and lanes right of the frame
+        // (offset pinned out of range) cost no branch: the eight stores sit in C2's basic block and the compiler counts
+        // them exactly in every s_waitcnt vmcnt behind them.
+        const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(O.pre, 0, (int)((uint32_t)H * (uint32_t)W * 12u), 0x00020000);
+        const uint32_t row_b = fin ? (uint32_t)W * 12u : 0u;                     // bytes per pre-warp image row (this lane's stride)
+        // V-pass register window as L / 2 VGPR pairs (2R + NB is even): element i = win2[i >> 1], half i & 1
+        f32x2 win2[L / 2];
 #pragma unroll
-        for (int i = 0; i < L; ++i) win[i] = 0.0f;
+        for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
+        // C1: append the eight H rows of the tile, form output rows j (x) and j + 1 (y) of each pair from window elements
+        // i = j .. j + 2R + 1 oldest first, shift the window down by NB
+        auto v_pass = [&](float (&blur)[NB]) {
+            const float* hcol = hrow + f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) win2[(2 * R + j) >> 1][j & 1] = hcol[j * CC_HROW];
+            f32x2 acc[NB / 2];
+#pragma unroll
+            for (int jp = 0; jp < NB / 2; ++jp) acc[jp] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < L; ++i)
+#pragma unroll
+                for (int jp = 0; jp < NB / 2; ++jp) {
+                    const int t = i - 2 * jp;
+                    if (t == 0) acc[jp].x = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].x);
+                    else if (t >= 1 && t <= 2 * R) PK_TAPS(acc[jp], win2[i >> 1], (i & 1) != 0, t);
+                    else if (t == 2 * R + 1) acc[jp].y = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].y);       // tap[2R] == tap[0]
+                }
+#pragma unroll
+            for (int jp = 0; jp < NB / 2; ++jp) { blur[2 * jp] = acc[jp].x; blur[2 * jp + 1] = acc[jp].y; }
+#pragma unroll
+            for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
+        };
         uint32_t offr[AO], offg[AO], offb[AO];
         RawRGB raw[AO];
 #pragma unroll
@@ -1468,10 +1557,11 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         // memory operations younger than the prefetched bytes as its back edge carries, so A's s_waitcnt vmcnt leaves
         // exactly the stores in flight
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *(volatile float*)trash = 0.0f;
+        for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b32(0u, pre_rsrc, 0xFFFFFF00u - 16u * (uint32_t)j, 0, 0);      // out of range: dropped
         int crow0 = 0, c2row0 = NB;
         int hb = y_begin - R;
-        for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
+        uint32_t off0 = fin ? (uint32_t)(y_begin - 2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R, float f), modulo 2^32 while that row is < 0
+        for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
                                         c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
             // ---- phase 1 ----
             float v[NB];
@@ -1480,63 +1570,61 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 int cr = c2row0 + j;
                 cr = cr >= CR ? cr - CR : cr;
                 if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
-                else v[j] = nlut[(cring[cr * TW + fcol] >> (8 * fch)) & 255u];
+                else v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
             }
             float blur[NB];
-            {
-                const float* hcol = hrow + f;
-#pragma unroll
-                for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
-                    blur[j] = acc;
-                }
-#pragma unroll
-                for (int i = 0; i < 2 * R; ++i) win[i] = win[i + NB];
-            }
+            v_pass(blur);
             STAMP(4);
+            {
+                float nv[AO][3];
 #pragma unroll
-            for (int u = 0; u < AO; ++u) a_stage(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u]);
+                for (int u = 0; u < AO; ++u) a_lookup(raw[u], nv[u]);
+#pragma unroll
+                for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u], nv[u]);
+            }
 #pragma unroll
             for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hb + NB, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
             STAMP(0);
             __syncthreads();
             STAMP(1);
             // ---- phase 2: C2 of block n-1 (output rows hb - NB - R + j), stage by stage over the eight rows ----
-            const float* gt = gn + ((n & 1) ^ 1) * NB * TW;
             const int yb = hb - NB - R;
+            // the per-pixel tiles of the helper wave and the row gains first: they depend on nothing in here, and their
+            // round trip then runs beside the two LUT gathers instead of behind them
+            const uint32_t gt_b = GN_B + (uint32_t)(((n & 1) ^ 1) * NB * TW * 4) + gcol4;
+            float sl[NB], gnv[NB];
+            double gv[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                sl[j] = __uint_as_float(LDS_AT(lds_u32_t, ROWTAB_B + (uint32_t)(((yb + j - y_begin) & 15) * 16)));
+                gv[j] = LDS_AT(lds_f64_t, GVIG_B + (uint32_t)(j * TW * 8) + gcol8);
+                gnv[j] = LDS_AT(lds_f32_t, gt_b + (uint32_t)(j * TW * 4));
+            }
 #pragma unroll
             for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);          // ref:611
 #pragma unroll
-            for (int j = 0; j < NB; ++j) v[j] = lut[lut_index_unit(v[j])] * cm;                      // ref:250-252
+            for (int j = 0; j < NB; ++j) v[j] = LDS_AT(lds_f32_t, LUT_B + ((uint32_t)lut_index_unit(v[j]) << 2)) * cm;                   // ref:250-252
 #pragma unroll
-            for (int j = 0; j < NB; ++j) v[j] = lut[LUT_STRIDE + lut_index(v[j])];                   // ref:261-262
+            for (int j = 0; j < NB; ++j) v[j] = LDS_AT(lds_f32_t, LUT_B + LUT_STRIDE * 4 + ((uint32_t)lut_index(v[j]) << 2));           // ref:261-262
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const float sl = __uint_as_float(rowtab[((yb + j - y_begin) & 15) * 4]);
-                const float r = clip01(v[j] * sl);                                                  // ref:617-624
-                double d = (double)r * gvig[j * TW + fcol];                                         // ref:626-628 (gain in [0,1]: no clip)
-                d = clip01(d + (double)gt[j * TW + fcol]);                                          // ref:646-647
+                const float r = clip01(v[j] * sl[j]);                                               // ref:617-624
+                double d = (double)r * gv[j];                                                       // ref:626-628 (gain in [0,1]: no clip)
+                d = clip01(d + (double)gnv[j]);                                                     // ref:646-647
                 v[j] = (float)d;
             }
+            {
+                uint32_t boff = off0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int y = yb + j;
-                float* dst = O.pre + (((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u + (uint32_t)f);
-                dst = (y >= y_begin && y < y_end && fin) ? dst : trash;
-#ifdef CC_EXP_NOSTORE
-                asm volatile("" : "+v"(v[j]));
-                (void)dst;
-#else
-                *dst = v[j];
-#endif
+                for (int j = 0; j < NB; ++j) {
+                    const int y = yb + j;
+                    const uint32_t oob = (y >= y_begin && y < y_end) ? 0u : 0xFFFFFFFFu;       // wave-uniform
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff | oob, 0, 0);
+                    boff += row_b;
+                }
             }
             STAMP(6);
-#pragma unroll
-            for (int u = 0; u < BO; ++u) { const int q = wave + 3 * u; if (q < NBI - B3) b_item(q); }
+            h_pass(wave);
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -1549,18 +1637,9 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 int cr = c2row0 + j;
                 cr = cr >= CR ? cr - CR : cr;
                 if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
-                else v[j] = nlut[(cring[cr * TW + fcol] >> (8 * fch)) & 255u];
+                else v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
             }
-            const float* hcol = hrow + f;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
-                blur[j] = acc;
-            }
+            v_pass(blur);
             __syncthreads();
             const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
             const int yb = hb - NB - R;
@@ -1617,8 +1696,13 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                     rt[0] = __float_as_uint(pf_scan); rt[1] = (uint32_t)__double2loint(pf_ny2); rt[2] = (uint32_t)__double2hiint(pf_ny2);
                 }
             }
+            {
+                float nv[A3R][3];
 #pragma unroll
-            for (int u = 0; u < A3; ++u) a_stage(NA - A3 + u, crow0, raw[u]);
+                for (int u = 0; u < A3; ++u) a_lookup(raw[u], nv[u]);
+#pragma unroll
+                for (int u = 0; u < A3; ++u) a_write(NA - A3 + u, crow0, raw[u], nv[u]);
+            }
             prefetch(hb + NB);
             STAMP(0);
             __syncthreads();
@@ -1628,16 +1712,11 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int y = min(max(hb - R + j, 0), H - 1);
-#ifdef CC_EXP_CHEAPG
-                const float z = __uint_as_float(0x3f000000u | (((uint32_t)y * (uint32_t)W + (uint32_t)xg) & 0xffffu));
-#else
                 const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
-#endif
                 gw[j * TW + lane] = z * P.noise_scale;
             }
             STAMP(6);
-#pragma unroll
-            for (int u = 0; u < B3; ++u) b_item(NBI - B3 + u);
+
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -1656,6 +1735,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         for (int i = 0; i < 8; ++i) d[i] = stamp_sum[i];
     }
 #endif
+#undef PK_TAPS
 #undef TAP
 }
 

@@ -4,7 +4,7 @@
 #include "crtfx_internal.h"
 
 #ifndef RR_R
-#error "compile with -DRR_R=<radius 1..30>"
+#error "compile with -DRR_R=<radius 1..30, or a bucket radius 36 / 42 / 48 / 64 / 80 / 96 / 112 / 128>"
 #endif
 
 namespace crtfx {
@@ -14,40 +14,42 @@ namespace crtfx {
 
 void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_rows, dim3 grid, size_t lds,
                                  hipStream_t s, int variant, hipEvent_t e0, hipEvent_t e1) {
-    if (variant == 4)       // full-chain gates, pre-warp image out: the column-owner kernel (uint8 frames)
+    // radius buckets (RR_R > 30) park more than 64 KiB of LDS in every build: opt in once per kernel and device
+#define CRTFX_BIG_LDS(kern)                                                                                              \
+    do {                                                                                                                  \
+        if (lds > 65536) {                                                                                                \
+            static std::atomic<bool> done[64];                                                                            \
+            int dev = 0;                                                                                                  \
+            (void)hipGetDevice(&dev);                                                                                     \
+            if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {                                     \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);                               \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
+#if RR_R <= 30
+    if (variant == 4) {     // full-chain gates, pre-warp image out: the column-owner kernel (uint8 frames)
         CRTFX_LAUNCH((k_phosphor_cc<RR_R, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
-    else if (variant == 5)  // ... half frames
-        CRTFX_LAUNCH((k_phosphor_cc<RR_R, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
-    else if (variant == 2)       // half frames, full-chain gates
+        return;
+    }
+#endif
+    if (variant == 2) {     // half frames, full-chain gates
+        CRTFX_BIG_LDS((k_phosphor_rr<RR_R, SF_FULL, 1>));
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
-    else if (variant == 1)
+    }
+    else if (variant == 1) {
+        CRTFX_BIG_LDS((k_phosphor_rr<RR_R, SF_FULL, 0>));
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+    }
     else if (variant == 3) {     // half frames, runtime gates
-        if (lds > 65536) {
-            static std::atomic<bool> raised16[64];      // zero-initialised; set once per device, from any thread
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64 || !raised16[dev].load(std::memory_order_acquire)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (dev >= 0 && dev < 64) raised16[dev].store(true, std::memory_order_release);
-            }
-        }
+        CRTFX_BIG_LDS((k_phosphor_rr<RR_R, SF_RUNTIME, 1>));
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     }
-    else {
-        if (lds > 65536) {      // large radii park up to 35 KB of graded centre pixels: above the default dynamic-LDS limit
-            static std::atomic<bool> raised[64];      // zero-initialised; set once per device, from any thread      // per device: one process may drive several GPUs
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (dev < 0 || dev >= 64 || !raised[dev].load(std::memory_order_acquire)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_phosphor_rr<RR_R, SF_RUNTIME, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (dev >= 0 && dev < 64) raised[dev].store(true, std::memory_order_release);
-            }
-        }
+    else {                       // runtime gates (large radii park up to 35 KB of graded centre pixels)
+        CRTFX_BIG_LDS((k_phosphor_rr<RR_R, SF_RUNTIME, 0>));
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_RUNTIME, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
     }
+#undef CRTFX_BIG_LDS
 }
 
 }  // namespace crtfx

@@ -18,6 +18,9 @@ from . import _lib, tables
 from .effects import Engine, Settings, _overlay_tensor, make_triad_mask, make_vignette
 
 
+_FRAME_DTYPE = np.dtype(_lib.CrtfxFrame)      # crtfx_frame as a numpy record (same layout: numpy takes it from the ctypes struct)
+
+
 @dataclass
 class RenderSettings:
     """process_video's effect keywords (ref:864-911) with the CLI defaults (ref:1155-1206)."""
@@ -104,20 +107,23 @@ class FramePipeline:
         self.static = settings.static_settings(self.h, self.w)
         self.engine.set_params(self.static)
         self.lib = self.engine.lib
+        self._scan_cache = {}
+        self._hold_scan = None
 
     # ---- per-frame records for frames [first, first+n) -------------------------------------
     def frame_records(self, first: int, n: int, noise_planes: Optional[torch.Tensor] = None):
+        """-> (records, keep-alive list).  The records are a numpy array laid out as crtfx_frame[n], filled column by
+        column (no per-frame Python work on the common path: at 4K the GPU finishes a frame in ~0.1 ms)."""
         rs, st = self.rs, self.static
-        idx = np.arange(first, first + n)
-        recs = (_lib.CrtfxFrame * n)()
-        hold = []
+        idx = np.arange(first, first + n, dtype=np.int64)
+        recs = np.zeros(n, dtype=_FRAME_DTYPE)
+        hold = [recs]
+        t_sec = idx.astype(np.float64) / float(self.fps)                                            # ref:1064, i / fps
         if st.scanline_strength > 0.0:
-            phases = [(int(i) / float(self.fps)) * rs.scanline_speed_px_s for i in idx]             # ref:1043
+            phases = t_sec * rs.scanline_speed_px_s                                                 # ref:1043
             if st.scanline_angle == 0.0 and st.scanline_thickness == 1.0:
-                rows = torch.from_numpy(tables.scanline_rows(self.h, st.scanline_strength, st.scanline_period_px, phases)).to(self.device)
-                hold.append(rows)
-                for j in range(n):
-                    recs[j].scan_row_dev = rows[j].data_ptr()
+                base, offs = self._scan_rows(phases)
+                recs["scan_row_dev"] = base + offs * 4
             else:
                 # slanted / shaped scanlines: the reference rebuilds an H x W float64 sin/pow mask per frame on the CPU
                 # (ref:308-328); here one small kernel per frame writes it on the device (crtfx_scanline_plane)
@@ -129,8 +135,7 @@ class FramePipeline:
                         _lib.check(self.lib, self.engine.ctx, self.lib.crtfx_scanline_plane(
                             self.engine.ctx, float(st.scanline_strength), omega, float(ph), tan_t, inv_sharp, planes[j].data_ptr(), stream))
                 hold.append(planes)
-                for j in range(n):
-                    recs[j].scan_plane_dev = planes[j].data_ptr()
+                recs["scan_plane_dev"] = planes.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(self.h * self.w * 4)
         flick = (self.engine.flags & _lib.F_FLICKER) != 0
         if rs.glitch_amp_px > 0 and rs.glitch_height_frac > 0.0:                                    # ref:835-859, render variant
             for j, i in enumerate(idx):
@@ -139,19 +144,47 @@ class FramePipeline:
                 if offs is not None:
                     t = torch.from_numpy(offs).to(self.device)
                     hold.append(t)
-                    recs[j].glitch_offs_dev, recs[j].glitch_y0, recs[j].glitch_cols = t.data_ptr(), int(y0), int(offs.shape[1])
-                    recs[j].glitch_seg_len = int(seg_len)
-        for j, i in enumerate(idx):
-            recs[j].flicker_factor = tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) if flick else 1.0  # ref:1064
-            recs[j].noise_seed = self.noise_seed & 0xFFFFFFFFFFFFFFFF
-            recs[j].frame_index = int(i)
-            if self.overlay is not None:
-                recs[j].overlay_rgba_dev, recs[j].overlay_after = self.overlay.data_ptr(), int(self.overlay_after)
-            if noise_planes is not None:
-                recs[j].noise_plane_dev = noise_planes[j].data_ptr()
+                    recs["glitch_offs_dev"][j], recs["glitch_y0"][j], recs["glitch_cols"][j] = t.data_ptr(), int(y0), int(offs.shape[1])
+                    recs["glitch_seg_len"][j] = int(seg_len)
+        if flick:
+            recs["flicker_factor"] = [tables.flicker_factor(st.flicker_strength, st.flicker_hz, int(i) / float(self.fps)) for i in idx]   # ref:1064
+        else:
+            recs["flicker_factor"] = 1.0
+        recs["noise_seed"] = np.uint64(self.noise_seed & 0xFFFFFFFFFFFFFFFF)
+        recs["frame_index"] = idx.astype(np.uint64)
+        if self.overlay is not None:
+            recs["overlay_rgba_dev"], recs["overlay_after"] = self.overlay.data_ptr(), int(self.overlay_after)
         if noise_planes is not None:
+            recs["noise_plane_dev"] = [noise_planes[j].data_ptr() for j in range(n)]
             hold.append(noise_planes)
         return recs, hold
+
+    def _scan_rows(self, phases: np.ndarray):
+        """Device address of the scanline row gains of every frame of a batch: (base pointer, float offset per frame).
+        The reference evaluates sin on float32(y) + float32(phase) (ref:213-217).  When every phase of the batch is an
+        integer (scanline_speed a multiple of fps: the CLI default 30 / 30) those sums are the integers y + phase
+        exactly, so ONE table g[k], k = min phase .. max phase + H - 1, holds every row of every frame — frame b's rows
+        are g[phase_b - min phase : ... + H], the same float32 values np.sin gives the reference — and a batch costs
+        H + n sines instead of H * n.  Otherwise: one (n, H) table per batch, as before."""
+        st = self.static
+        ph32 = phases.astype(np.float32)
+        if np.all(ph32 == np.rint(ph32)) and float(np.abs(ph32).max(initial=0.0)) + self.h < 2.0 ** 24:
+            lo = int(ph32.min())
+            hi = int(ph32.max())
+            key = (lo, hi)
+            hit = self._scan_cache.get(key)
+            if hit is None:
+                k = np.arange(lo, hi + self.h, dtype=np.float32)
+                g = tables.scanline_rows_at(k, st.scanline_strength, st.scanline_period_px)      # scanline_rows' expression on the sums themselves
+                hit = torch.from_numpy(g).to(self.device)
+                if len(self._scan_cache) >= 8:
+                    self._scan_cache.pop(next(iter(self._scan_cache)))
+                self._scan_cache[key] = hit
+            self._hold_scan = hit
+            return hit.data_ptr(), (ph32.astype(np.int64) - lo).astype(np.uint64)
+        rows = torch.from_numpy(tables.scanline_rows(self.h, st.scanline_strength, st.scanline_period_px, phases)).to(self.device)
+        self._hold_scan = rows
+        return rows.data_ptr(), np.arange(len(phases), dtype=np.uint64) * np.uint64(self.h)
 
     def run(self, frames: torch.Tensor, first_index: int = 0, state: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, noise_planes: Optional[torch.Tensor] = None,
@@ -169,6 +202,8 @@ class FramePipeline:
         if p > 0.0 and state is None:
             state = torch.empty((self.h, self.w, 3), dtype=torch.float32, device=self.device)
         stride = self.h * self.w * 3 * frames.element_size()
+        if isinstance(recs, np.ndarray):
+            recs = recs.ctypes.data_as(ctypes.POINTER(_lib.CrtfxFrame))
         with torch.cuda.device(self.device):
             rc = self.lib.crtfx_process_batch(
                 self.engine.ctx, frames.data_ptr(), stride, out.data_ptr(), stride, n, recs,
@@ -176,7 +211,7 @@ class FramePipeline:
                 local_states.data_ptr() if local_states is not None else None,
                 torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.lib, self.engine.ctx, rc)
-        self._hold = hold      # keep per-frame tables alive until the next run replaces them
+        self._hold = (hold, self._hold_scan)      # keep per-frame tables alive until the next run replaces them
         return out, (state if p > 0.0 else None)
 
     # ---- profiling hooks (HIP events recorded by the library on the launch stream) ----------

@@ -119,6 +119,14 @@ def scanline_rows(h: int, strength: float, period_px: float, phases) -> np.ndarr
     return np.ascontiguousarray(1.0 - strength * s)
 
 
+def scanline_rows_at(k: np.ndarray, strength: float, period_px: float) -> np.ndarray:
+    """The expression of scanline_rows on given float32 values of (y + phase): used when those sums are exact integers
+    (pipeline._scan_rows), so one table serves every frame of a batch."""
+    k = np.asarray(k, dtype=np.float32)
+    s = 0.5 * (1.0 + np.sin((2.0 * np.pi / max(1e-6, period_px)) * k))
+    return np.ascontiguousarray(1.0 - strength * s)
+
+
 def scanline_plane(h: int, w: int, strength: float, period_px: float, phase_px: float, angle_deg: float, thickness: float) -> np.ndarray:
     """make_scanline_mask_2d (ref:308-328) — only used when angle != 0 or thickness != 1."""
     if strength <= 0.0:

@@ -157,3 +157,15 @@ def test_reference_built_masks_are_recognised():
     tm[0, 0, 0] = 0.5                                   # rebuilt in place: no longer row-identical
     assert effects._recognise_triad(tm) is tm
     assert len(effects._RECOGNISED) <= effects._RECOGNISED_MAX
+
+
+def test_shared_scanline_table_for_integer_phases():
+    """pipeline._scan_rows: with integer phases (scanline_speed a multiple of fps) float32(y) + float32(phase) is the
+    integer y + phase exactly, so one table over k = y + phase holds every frame's rows bit for bit."""
+    from pythoncrt_amd import tables
+    h = 270
+    for strength, period in ((0.6, 2.0), (0.4, 2.7), (1.0, 1.0)):
+        phases = [float(i) for i in range(100, 140)]
+        rows = tables.scanline_rows(h, strength, period, phases)
+        g = tables.scanline_rows_at(np.arange(100, 139 + h, dtype=np.float32), strength, period)
+        assert g.dtype == np.float32 and all(np.array_equal(rows[b], g[b:b + h]) for b in range(len(phases)))

@@ -150,10 +150,11 @@ def test_scanlines_2d_and_vignette_array(pc):
 
 
 @pytest.mark.parametrize("hw", SIZES + [(150, 64)])
-@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 4.4, 6.5, 8.3, 10.0, 12.0])       # radii 9 4 2 1 12 | 13 20 25 30 (register window) | 36 (LDS ring)
+@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 4.4, 6.5, 8.3, 10.0, 12.0, 20.0, 27.0, 40.0])       # radii 9 4 2 1 12 | 13 20 25 30 (one build each) | 36 60 81 120 (buckets 48 64 96 128)
 def test_bloom_bit_exact(pc, hw, sigma):
-    """a5: separable Gaussian (LDS strips, ring H-pass, register-blocked V-pass) — same fmaf
-    accumulation order as the oracle, so equal to the last bit, borders included."""
+    """a5: separable Gaussian (LDS strips, H pass, register-window V pass) — same fmaf accumulation order as the
+    oracle, so equal to the last bit, borders included.  Radii beyond 30 run the next bucket's build on zero-padded
+    taps (crtfx_internal.h): still the same sums — the reference takes any sigma (ref:609-610)."""
     frame = make_frame(*hw, seed=9)
     got, exp = run_both(pc, frame, dict(bloom_sigma=sigma, bloom_strength=0.25, aberration_px=1))
     assert_bit_exact(got, exp)
@@ -306,8 +307,9 @@ def test_errors_are_loud(pc):
         pc.apply_static_effects(frame, 0.0, pc.make_triad_mask(10, 10, 0.3), *a[3:])
     with pytest.raises(ValueError):
         pc.apply_static_effects(*a, text_overlay_rgba=np.zeros((10, 10, 3), np.uint8))       # RGBA plane wanted
+    pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                            # sigma 40 -> radius 120: runs (bucket 128)
     with pytest.raises(Exception, match="radius"):
-        pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                        # sigma 40 -> radius 120 > 64
+        pc.apply_static_effects(*a[:6], 50.0, *a[7:])                                        # sigma 50 -> radius 150 > 128
 
 
 # ---- BASELINE full sizes: size-independent properties ------------------------------------------
@@ -368,7 +370,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
     frame = make_frame(h, w, seed=60, kind="grad")
     tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
     outs = {}
-    for name, opts in (("folded", {}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1})):
+    for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1})):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
@@ -392,7 +394,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(st.cpu().numpy())
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("no_cc", "runtime_flags", "generic"):
+    for name in ("cc", "no_cc", "runtime_flags", "generic"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
 

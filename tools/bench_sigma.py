@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Frames/s of the 4K (or --h/--w) full chain as a function of the bloom sigma (radius = round(3 sigma)):
-shows where the register-window kernel (radius <= 12) hands over to the general LDS-ring kernel."""
+one build per radius up to 30, then the radius buckets 48 / 64 / 96 / 128 on zero-padded taps."""
 import argparse, dataclasses, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pythoncrt_amd.pipeline import FramePipeline, baseline_config
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--sigmas", type=float, nargs="+", default=[1.2, 3.0, 4.0, 4.5, 6.5, 10.0])
+ap.add_argument("--sigmas", type=float, nargs="+", default=[1.2, 3.0, 4.0, 4.5, 6.5, 8.3, 10.0, 10.5, 12.0, 16.0, 17.0, 21.0, 22.0, 32.0, 33.0, 42.0])
 ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int, default=3840)
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--overlay", choices=["none", "before", "after"], default="none", help="a text overlay blended before / after the effects")
