@@ -168,20 +168,21 @@ class FramePipeline:
         H + n sines instead of H * n.  Otherwise: one (n, H) table per batch, as before."""
         st = self.static
         ph32 = phases.astype(np.float32)
-        if np.all(ph32 == np.rint(ph32)) and float(np.abs(ph32).max(initial=0.0)) + self.h < 2.0 ** 24:
+        if np.all(ph32 == np.rint(ph32)) and float(np.abs(ph32).max(initial=0.0)) + self.h + 70000 < 2.0 ** 24:
             lo = int(ph32.min())
             hi = int(ph32.max())
-            key = (lo, hi)
-            hit = self._scan_cache.get(key)
-            if hit is None:
-                k = np.arange(lo, hi + self.h, dtype=np.float32)
+            hit = self._scan_cache.get("table")
+            if hit is None or lo < hit[0] or hi + self.h > hit[1]:
+                # a table that also covers the batches to come (a render's phases only grow): a host -> device copy from
+                # pageable memory waits for everything already queued on the stream, i.e. it would serialise the host
+                # with the GPU once per batch
+                top = hi + self.h + 65536
+                k = np.arange(lo, top, dtype=np.float32)
                 g = tables.scanline_rows_at(k, st.scanline_strength, st.scanline_period_px)      # scanline_rows' expression on the sums themselves
-                hit = torch.from_numpy(g).to(self.device)
-                if len(self._scan_cache) >= 8:
-                    self._scan_cache.pop(next(iter(self._scan_cache)))
-                self._scan_cache[key] = hit
-            self._hold_scan = hit
-            return hit.data_ptr(), (ph32.astype(np.int64) - lo).astype(np.uint64)
+                hit = (lo, top, torch.from_numpy(g).pin_memory().to(self.device, non_blocking=True))
+                self._scan_cache["table"] = hit
+            self._hold_scan = hit[2]
+            return hit[2].data_ptr(), (ph32.astype(np.int64) - hit[0]).astype(np.uint64)
         rows = torch.from_numpy(tables.scanline_rows(self.h, st.scanline_strength, st.scanline_period_px, phases)).to(self.device)
         self._hold_scan = rows
         return rows.data_ptr(), np.arange(len(phases), dtype=np.uint64) * np.uint64(self.h)

@@ -105,6 +105,8 @@ class ShardedRender:
         self.parallel_hop = self.p > 0.0 and (self.p ** shard.chunk) < 2.0 ** -24
         self.overlap = bool(overlap) and self.parallel_hop and shard.world > 1
         self.timing = bool(timing)
+        self._worker = None           # staged (gloo + device tensors) overlapped hops run on one worker thread
+        self._last_transport_s = None
         self._pending = None          # overlapped mode: the round whose hop is in flight
         self._marks = []              # timing: per finished round (scan events, hop-wait events + host seconds, fix-up events)
 
@@ -113,6 +115,55 @@ class ShardedRender:
         # RCCL moves device tensors directly (one xGMI hop).  gloo has no device point-to-point: stage through the
         # host (CPU tests, and rehearsals of several ranks on one GPU).
         return like.is_cuda and self.dist.get_backend(self.group) == "gloo"
+
+    def _post_staged_async(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
+        """gloo rehearsal of a device hop, off the calling thread: the state frame is copied to pinned host memory on a
+        side stream once the scan that produces it has finished (an event, not a host sync — the compute stream keeps
+        its queue), then sent / received by ONE worker thread in round order.  Returns a handle for _complete."""
+        import queue
+        import threading
+        if self._worker is None:
+            self._jobs = queue.Queue()
+
+            def run():
+                while True:
+                    job = self._jobs.get()
+                    if job is None:
+                        return
+                    fn, box, done = job
+                    try:
+                        box.append(fn())
+                    except BaseException as e:      # surfaced by _complete on the calling thread
+                        box.append(e)
+                    done.set()
+            self._worker = threading.Thread(target=run, daemon=True)
+            self._worker.start()
+            self._side = torch.cuda.Stream(device=recv_like.device)
+        ready = torch.cuda.Event()
+        ready.record()                                   # behind the scan on the compute stream
+        d, group, side = self.dist, self.group, self._side
+        host_send = torch.empty(recv_like.shape, dtype=recv_like.dtype, pin_memory=True) if (dst is not None and send is not None) else None
+        host_recv = torch.empty(recv_like.shape, dtype=recv_like.dtype, pin_memory=True) if src is not None else None
+
+        def job():
+            import time as _t
+            t0 = _t.perf_counter()
+            ops = []
+            if host_send is not None:
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    host_send.copy_(send, non_blocking=True)
+                side.synchronize()
+                ops.append(d.P2POp(d.isend, host_send, dst, group))
+            if host_recv is not None:
+                ops.append(d.P2POp(d.irecv, host_recv, src, group))
+            t1 = _t.perf_counter()
+            for w in (d.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            return host_recv, _t.perf_counter() - t1, t1 - t0
+        box, done = [], threading.Event()
+        self._jobs.put((job, box, done))
+        return ("async", box, done)
 
     def _post(self, send: Optional[torch.Tensor], recv_like: torch.Tensor, src: Optional[int], dst: Optional[int]):
         """Start the exchange; returns (works, recv buffer or None, staged)."""
@@ -127,8 +178,16 @@ class ShardedRender:
         works = d.batch_isend_irecv(ops) if ops else []
         return works, recv, stage
 
-    @staticmethod
-    def _complete(works, recv, stage, device):
+    def _complete(self, works, recv, stage, device):
+        if isinstance(works, str) and works == "async":      # (tag, box, done) from _post_staged_async
+            box, done = recv, stage
+            done.wait()
+            res = box[0]
+            if isinstance(res, BaseException):
+                raise res
+            host_recv, transport_s, stage_s = res
+            self._last_transport_s = transport_s
+            return host_recv.to(device, non_blocking=True) if host_recv is not None else None
         for r in works:
             r.wait()            # RCCL: orders the current stream behind the transfer (no host block); gloo: host wait
         return recv.to(device) if (stage and recv is not None) else recv
@@ -152,7 +211,7 @@ class ShardedRender:
         if not self._marks:
             return None
         torch.cuda.synchronize()
-        scan = hop = fix = host = 0.0
+        scan = hop = fix = host = tr = 0.0
         n = 0
         for m in self._marks:
             if m["scan"][0] is None:
@@ -161,6 +220,7 @@ class ShardedRender:
             hop += m["hop"][0].elapsed_time(m["hop"][1]) * 1e3 if m["hop"][0] is not None else 0.0
             fix += m["fix"][0].elapsed_time(m["fix"][1]) * 1e3 if m["fix"][0] is not None else 0.0
             host += m["hop_host_s"]
+            tr += m.get("transport_s") or 0.0
             n += 1
         if not n:
             return None
@@ -168,6 +228,7 @@ class ShardedRender:
         return {"rounds": n, "chunk": self.shard.chunk, "overlap": self.overlap, "parallel_hop": self.parallel_hop,
                 "scan_us": round(scan / n, 1), "hop_stall_us": round(hop / n, 1), "fixup_us": round(fix / n, 1),
                 "hop_host_wait_us": round(host / n * 1e6, 1),
+                "hop_transport_us": round(tr / n * 1e6, 1) if tr else None,      # staged rehearsal only: gloo's host-side transfer of the frame
                 "hop_plus_fixup_share": round((hop + fix) / tot, 4) if tot > 0 else None,
                 "fixup_frames": min(self.shard.chunk, settle_frames(self.p, 2.0 ** -26))}
 
@@ -208,6 +269,8 @@ class ShardedRender:
         if not self._staged(final_local):
             # RCCL: the transfer is enqueued behind the scan now and runs beside whatever the compute stream does next
             rec["posted"] = self._post(final_local if dst is not None else None, final_local, src, dst)
+        elif final_local.is_cuda:
+            rec["posted"] = self._post_staged_async(final_local if dst is not None else None, final_local, src, dst)
         prev, self._pending = self._pending, rec
         if prev is not None:
             done.append(self._finish(prev))
@@ -240,7 +303,8 @@ class ShardedRender:
             self.engine.correct(rec["local"][:k], carry, p, rec["out"][:k])
             f1 = self._ev(final_local)
         if self.timing:
-            self._marks.append({"scan": rec["scan"], "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s})
+            self._marks.append({"scan": rec["scan"], "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s,
+                                "transport_s": self._last_transport_s})
         return rec["round"], rec["out"]
 
     def flush(self):

@@ -1,49 +1,88 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>_* (tools/collect_profiles.sh) into the tracked files under profiles/:
-<tag>_kernel_stats.csv, <tag>_pmc.json, <tag>_bench.json and profiles/traffic.json (HBM bytes per frame
-from the separate FETCH_SIZE / WRITE_SIZE passes; KiB -> bytes, FETCH_SIZE of the k_warp kernels doubled: see DESIGN.md 6)."""
-import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_z"
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats rows of the crtfx kernels
+  <tag>_pmc.json           separate --pmc passes, mean per launch
+  <tag>_bench.json         the bench line of the same box
+  <tag>_fetch_calibration.txt   FETCH_SIZE on a known cold byte count in the chain's load shapes
+  traffic.json / valu.json what bench.py's roofline.traffic / roofline.valu read — each entry carries the sha1 of the kernel
+                           sources it was measured on (bench.py ignores it when that differs from the build under test), the
+                           tag, the batch, and BOTH the as-reported and the corrected byte counts.
+Usage: python tools/summarise_profiles.py <tag> [configN]"""
+import collections, csv, glob, json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_z"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "config3"
 os.makedirs("profiles", exist_ok=True)
 newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]      # gpurun_out/ accumulates across calls
+
+
+def counters(part):
+    fs = newest(glob.glob(f"gpurun_out/{tag}_{part}/**/*counter_collection.csv", recursive=True))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in (csv.DictReader(open(fs[0])) if fs else []):
+        agg[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+
+
 ks = newest(glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True))
 if ks:
     rows = [r for r in csv.reader(open(ks[0]))]
-    keep = [rows[0]] + [r for r in rows[1:] if "crtfx" in r[0]]
-    csv.writer(open(f"profiles/{tag}_kernel_stats.csv", "w")).writerows(keep)
+    csv.writer(open(f"profiles/{tag}_kernel_stats.csv", "w")).writerows([rows[0]] + [r for r in rows[1:] if "crtfx" in r[0]])
 pmc = {}
-for part in ("fetch", "write", "sq"):
-    fs = newest(glob.glob(f"gpurun_out/{tag}_{part}/**/*counter_collection.csv", recursive=True))
-    if not fs:
-        continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for row in csv.DictReader(open(fs[0])):
-        k = row["Kernel_Name"]
+for part in ("fetch", "write", "sq", "sq2"):
+    for k, d in counters(part).items():
         if "crtfx" in k:
-            agg[k.split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, d in agg.items():
-        pmc.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in d.items()})
+            pmc.setdefault(k, {}).update(d)
 json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
-# frames per launch of each kernel class, from the bench line of the same collection (PMC values are per launch)
-fpl = {}
+
+# ---- FETCH_SIZE calibration: reported KiB vs the bytes each shape really read (2 GiB, cold) --------------------------------
+calib = {k: d.get("FETCH_SIZE", 0.0) * 1024 for k, d in counters("calib").items()}
+known = {}
+log = f"gpurun_out/{tag}_calib.log"
+if os.path.exists(log):
+    m = re.search(r"k_px12 (\d+)\s+k_byte3 (\d+)\s+k_dword (\d+)", open(log).read())
+    if m:
+        known = {"k_px12": int(m.group(1)), "k_byte3": int(m.group(2)), "k_dword": int(m.group(3))}
+ratio = {k: (calib[n] / known[k]) for k in known for n in calib if n.startswith(k) and known[k]}
+with open(f"profiles/{tag}_fetch_calibration.txt", "w") as f:
+    f.write("FETCH_SIZE (rocprofv3 --pmc, KiB -> bytes) against a known byte count read ONCE from a cold 2 GiB buffer (8x the Infinity Cache)\n"
+            "tools/ubench/fetch_calib.hip; shapes: k_px12 = 12 B/lane float3 pixels (k_warp taps), k_byte3 = 3 single-byte loads per lane at a\n"
+            "3-byte lane stride (k_phosphor frame bytes), k_dword = 4 B/lane.\n")
+    for k in known:
+        n = next((x for x in calib if x.startswith(k)), None)
+        if n:
+            f.write(f"  {k:8s} read {known[k] / 1e6:9.1f} MB   FETCH_SIZE reports {calib[n] / 1e6:9.1f} MB   ratio {ratio[k]:.3f}\n")
+    f.write("bench.py's roofline.traffic divides a kernel's reported FETCH_SIZE by the ratio of its load shape (a ratio within 5 % of 1 is taken as 1).\n")
+fix = lambda r: 1.0 if (r is None or abs(r - 1.0) < 0.05 or r <= 0) else 1.0 / r
+fetch_fix = {"k_warp": fix(ratio.get("k_px12")), "k_phosphor": fix(ratio.get("k_byte3"))}
+
+# ---- frames per launch of each kernel class, from the bench line of the same collection (PMC values are per launch) ------
+fpl, bench = {}, {}
 if os.path.exists(f"gpurun_out/{tag}_bench.json"):
-    rl = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1]).get("roofline", {})
-    fpl = {k: v["frames_per_launch"] for k, v in rl.get("kernels", {}).items()}
-cls = lambda name: "k_phosphor" if ("k_phosphor" in name or "k_point" in name or "k_half" in name) else "k_warp"
-# gfx950: FETCH_SIZE tallies 128-B requests at 64 B.  Calibrated on this code's own patterns (profiles/r01_z_fetch_calibration.txt):
-# the 12-B-per-lane reads of the k_warp kernels report 0.44 x a known byte count -> doubled; the byte loads of k_phosphor / k_point
-# are uncalibrated and taken as reported; WRITE_SIZE is exact.
-fetch_fix = lambda name: 2.0 if cls(name) == "k_warp" else 1.0
-traffic = sum((d.get("FETCH_SIZE", 0) * fetch_fix(k) + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls(k), 1.0) for k, d in pmc.items())      # bytes per FRAME
-tj = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
-tj[cfg] = int(traffic)
-tj[cfg + "_detail_bytes_per_launch_as_reported"] = {k: dict({c: int(v * 1024) for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")},
-                                             frames_per_launch=fpl.get(cls(k), 1.0)) for k, d in pmc.items()}
-tj.pop(cfg + "_detail_bytes", None)
-tj.pop(cfg + "_detail_bytes_per_launch", None)
-json.dump(tj, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
-if os.path.exists(f"gpurun_out/{tag}_bench.json"):
+    bench = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])
+    fpl = {k: v["frames_per_launch"] for k, v in bench.get("roofline", {}).get("kernels", {}).items()}
     shutil.copy(f"gpurun_out/{tag}_bench.json", f"profiles/{tag}_bench.json")
-print(json.dumps(tj, indent=1))
+cls = lambda name: "k_phosphor" if ("k_phosphor" in name or "k_point" in name or "k_half" in name) else "k_warp"
+import bench as bench_mod      # source_hash(): sha1 of the kernel sources
+src = bench_mod.source_hash()
+raw = sum((d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+cor = sum((d.get("FETCH_SIZE", 0) * fetch_fix[cls(k)] + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+tj = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
+tj = {k: v for k, v in tj.items() if isinstance(v, dict) and "source_hash" in v}      # drop round-1 style entries
+tj[cfg] = {"bytes_per_frame_as_reported": int(raw), "bytes_per_frame_corrected": int(cor), "source_hash": src, "tag": tag, "batch": 8,
+           "correction": {"FETCH_SIZE multiplier by kernel class (1 / calibration ratio)": fetch_fix, "WRITE_SIZE": "exact",
+                          "calibration": f"profiles/{tag}_fetch_calibration.txt"},
+           "per_launch_as_reported": {k: dict({c: int(v * 1024) for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")},
+                                              frames_per_launch=fpl.get(cls(k), 1.0)) for k, d in pmc.items()}}
+json.dump(tj, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
+# VALU wave-instructions per frame + the clock the run held (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+valu = sum(d.get("SQ_INSTS_VALU", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+vj = json.load(open("profiles/valu.json")) if os.path.exists("profiles/valu.json") else {}
+vj[cfg] = {"valu_wave_insts_per_frame": int(valu), "clock_ghz": 2.4, "source_hash": src, "tag": tag,
+           "per_launch": {k: {c: d[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES") if c in d} for k, d in pmc.items()}}
+json.dump(vj, open("profiles/valu.json", "w"), indent=1, sort_keys=True)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch_as_reported"} for k, v in tj.items()}, indent=1))
 print(open(f"profiles/{tag}_kernel_stats.csv").read() if ks else "no kernel stats")
+print(open(f"profiles/{tag}_fetch_calibration.txt").read())
