@@ -160,6 +160,38 @@ def test_bloom_bit_exact(pc, hw, sigma):
     assert_bit_exact(got, exp)
 
 
+@pytest.mark.parametrize("sigma", [1.2, 3.0])        # BASELINE configs 2 and 3
+def test_gpu_within_every_opencv_variant(pc, sigma):
+    """The OpenCV-backed stages are parity-unpinned (no reference-held vector, cv2 not importable).  The oracle restates one
+    accumulation form; oracle/crt_oracle.c also restates the OTHER forms OpenCV's C++ engine contains (symmetric-paired
+    column taps with / without FMA, SymmRowSmall, multiply-then-add, a contracted remap sum, convertScaleAbs in double).
+    Whichever of them a given cv2 build takes, the GPU must stay within the spread tests/test_oracle_variants.py measures:
+    float image (no warp) equal to each variant except where a triad-LUT index flips (< 1e-4 of the samples, <= 1e-3);
+    uint8 frame with the warp <= 1 LSB on < 0.1 % of the samples (the warp path's own bar)."""
+    h, w = 135, 240
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = np.stack([xx * 255.0 / w, yy * 255.0 / h, (xx + yy) * 255.0 / (h + w)], axis=2).astype(np.int32)
+    frame = np.clip((rng.integers(0, 256, (h, w, 3), dtype=np.int32) + grad) // 2, 0, 255).astype(np.uint8)
+    plane = np.random.default_rng(9).standard_normal((h, w), dtype=np.float32)
+    cfg = dict(scanline_strength=0.6, triad=(0.35, 0.5), aberration_px=1, bloom_sigma=sigma, bloom_strength=0.25, vignette=0.25,
+               noise_strength=1.5, scanline_phase_px=1.25)
+    got, exp0 = run_both(pc, frame, cfg, noise_plane=plane)
+    assert_bit_exact(got, exp0)                                   # the oracle's own form: to the bit
+    tm_g, vg_g = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    tm_o, vg_o = orc.make_triad_mask(h, w, 0.35, 0.5), orc.make_vignette(h, w, 0.25)
+    a = lambda tm, vg: (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 0.0, None, 2.0, 1.25, False, 1)
+    u8_gpu, _ = pc.apply_crt_effect(*a(tm_g, vg_g), warp_strength=0.15, noise_plane=plane)
+    for name, kw in orc.OPENCV_VARIANTS.items():
+        with orc.opencv_variant(**kw):
+            _, exp = run_both(pc, frame, cfg, noise_plane=plane)
+            u8_o, _ = orc.apply_crt_effect(*a(tm_o, vg_o), warp_strength=0.15, noise_plane=plane)
+        d = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+        assert d.max() <= 1e-3 and (d > 1e-6).mean() < 1e-4, (name, float(d.max()), float((d > 1e-6).mean()))
+        du = np.abs(np.asarray(u8_gpu).astype(np.int16) - u8_o.astype(np.int16))
+        assert du.max() <= 1 and (du != 0).mean() < 1e-3, (name, int(du.max()), float((du != 0).mean()))
+
+
 def test_bloom_threshold_and_strength(pc):
     frame = make_frame(64, 96, seed=10, kind="grad")
     got, exp = run_both(pc, frame, dict(bloom_sigma=3.0, bloom_strength=1.5, bloom_threshold=0.4), brightness=0.05, contrast=1.1)
