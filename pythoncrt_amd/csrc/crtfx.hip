@@ -346,7 +346,7 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
     ProfEv pe(c, 1, g);
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
     // plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend)
-    bool lean = !identity && !c->force_generic;
+    bool lean = !identity && !c->force_generic && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);      // k_warp_lean reads the image through a 32-bit buffer resource
     for (int j = 0; j < g && lean; ++j) {
         const KOut& o = wg.o[j];
         lean = !o.overlay_after && !o.glitch_offs && !o.out_f32 && o.blend == wg.o[0].blend &&

@@ -363,6 +363,19 @@ __device__ __forceinline__ uint32_t quant_u8(float v) {
     return (uint32_t)min(max(r, 0), 255);
 }
 
+// a15 of one RGB pixel packed r | g<<8 | b<<16 with three v_cvt_pk_u8_f32: the instruction rounds to nearest-even and
+// saturates to 0..255 — the same function as quant_u8 for every float32 (tools/ubench/cvt_pk_u8_test.hip: all 1.07 G
+// values of [0, 1.25], the huge / inf / nan range and the negatives, 0 mismatches), in one 3.7-cycle instruction per
+// channel instead of multiply-free rint + convert + clamp + shift + or.
+__device__ __forceinline__ uint32_t quant_u8x3(float v0, float v1, float v2) {
+    uint32_t d = 0;
+    const float s0 = fabsf(v0 * 255.0f), s1 = fabsf(v1 * 255.0f), s2 = fabsf(v2 * 255.0f);
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(d) : "v"(s0));
+    asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(d) : "v"(s1));
+    asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(d) : "v"(s2));
+    return d;
+}
+
 // a15 for half frames: |x*255| narrowed to half (convertScaleAbs without the integer rounding)
 __device__ __forceinline__ uint32_t quant_f16(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)fabsf(v * 255.0f)); }   // RNE narrowing
 
@@ -396,6 +409,28 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
     } else if (lane < valid_px) {
         uint8_t* p = out + row_byte0 + (size_t)lane * 3;
         p[0] = (uint8_t)packed; p[1] = (uint8_t)(packed >> 8); p[2] = (uint8_t)(packed >> 16);
+    }
+}
+
+// The same through a raw buffer resource over the output frame (k_warp_lean; frame bytes < 2^31): 32-bit offsets, and the
+// dwords past the row segment's end are given an out-of-range offset, which the hardware drops — no byte tail, no 64-bit
+// address arithmetic.  Needs the segment dword-aligned with a whole number of dwords (W % 4 == 0); else the byte form.
+__device__ __forceinline__ void store_row_u8_buf(__amdgpu_buffer_rsrc_t rs, uint32_t row_byte0, int lane, int valid_px, uint32_t packed, bool aligned) {
+    if (aligned) {                           // wave-uniform
+        const int j = lane;                // dword index in the 192-byte segment
+        const int a = (4 * j) / 3;         // first contributing pixel
+        const int o = (4 * j) - 3 * a;     // byte offset inside that pixel (0..2)
+        const uint32_t lo = __shfl(packed, a & 63);
+        const uint32_t hi = __shfl(packed, (a + 1) & 63);
+        const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 24);
+        const uint32_t dw = (uint32_t)(v >> (8 * o));
+        const uint32_t off = (4 * j + 4 <= valid_px * 3) ? row_byte0 + 4u * (uint32_t)j : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b32(dw, rs, off, 0, 0);
+    } else {
+        const uint32_t off = lane < valid_px ? row_byte0 + 3u * (uint32_t)lane : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)packed, rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 8), rs, off + 1u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 16), rs, off + 2u, 0, 0);
     }
 }
 
@@ -1859,6 +1894,34 @@ __device__ __forceinline__ WarpTaps warp_load(const KParams& P, const float* __r
     t.u10 = (xin0 && yin1) ? wy1 * wx0 : 0.0f; t.u11 = (xin1 && yin1) ? wy1 * wx1 : 0.0f;
     return t;
 }
+// The same four taps through a raw buffer resource over the pre-warp image (H * W * 12 bytes < 2^31: the host routes
+// larger frames to the general k_warp).  One 32-bit byte offset per row pair, the right-hand tap in the instruction's
+// immediate; a tap ABOVE or BELOW the image is an offset outside the buffer, for which the hardware's range check returns
+// 0 — cv2.remap's border value — so only the x range needs masking (the linear offset of a column left / right of the
+// image lands in a neighbouring row): the mask zeroes wx0 / wx1 before the four weights are formed.  Same products, same
+// sums as warp_load + warp_combine (a zeroed weight times a finite tap and a finite weight times a zero tap are both +0);
+// what goes is the 64-bit address arithmetic and the clamp / compare / select ladder: k_warp_lean was 75 % VALU-bound
+// by cost (tools/isa_cost.py: 932 cycles per thread, 52 % of it integer).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ F3 buf_load_px(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+    return F3{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])};
+}
+__device__ __forceinline__ WarpTaps warp_load_buf(const KParams& P, __amdgpu_buffer_rsrc_t rs, int ix, int iy, int fx, int fy) {
+    WarpTaps t;
+    const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
+    const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
+    const float mx0 = (unsigned)ix < (unsigned)P.W ? wx0 : 0.0f, mx1 = (unsigned)(ix + 1) < (unsigned)P.W ? wx1 : 0.0f;
+    t.u00 = wy0 * mx0; t.u01 = wy0 * mx1; t.u10 = wy1 * mx0; t.u11 = wy1 * mx1;
+    // clamps keep the offset arithmetic inside 32 bits: iy to [-2, H] (both rows of the pair stay outside when iy is), ix to
+    // [-1, W] (the masks above come from the unclamped ix)
+    const int ixc = min(max(ix, -1), P.W), iyc = min(max(iy, -2), P.H);
+    const uint32_t off_a = (uint32_t)(iyc * P.W + ixc) * 12u;                    // a negative offset (rows -2, -1) wraps far past the buffer's end
+    const uint32_t off_b = off_a + (uint32_t)P.W * 12u;
+    t.A = buf_load_px(rs, off_a); t.B = buf_load_px(rs, off_a + 12u);
+    t.C = buf_load_px(rs, off_b); t.D = buf_load_px(rs, off_b + 12u);
+    return t;
+}
 template <typename T>
 __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T& o2) {
     o0 = (((T)t.A.x * (T)t.u00 + (T)t.B.x * (T)t.u01) + (T)t.C.x * (T)t.u10) + (T)t.D.x * (T)t.u11;
@@ -1878,6 +1941,8 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
     const int x = min(x0 + lane, P.W - 1);
     const bool live = x0 + lane < P.W;
     const float* state_in = O.state_in ? O.state_in : O.state;
+    const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 12u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, O.out_u8 ? (int)((uint32_t)P.H * (uint32_t)P.W * 3u) : 0, 0x00020000);
     WarpTaps taps[ROWS];
     F3 st[ROWS];
 #pragma unroll
@@ -1885,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
         const int y = min(ybase + 4 * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
         int ix, iy, fx, fy;
         warp_coords(P, y, x, ix, iy, fx, fy);
-        taps[r] = warp_load(P, pre, ix, iy, fx, fy);
+        taps[r] = warp_load_buf(P, pre_rs, ix, iy, fx, fy);
         if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
 #pragma unroll
@@ -1905,7 +1970,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
             if constexpr (PIX == CRTFX_PIX_F16) {
                 store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
             } else {
-                store_row_u8(O.out_u8, ((size_t)y * P.W + x0) * 3, lane, min(64, P.W - x0), quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16));
+                store_row_u8_buf(out_rs, ((uint32_t)y * (uint32_t)P.W + (uint32_t)x0) * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), (P.W & 3) == 0);
             }
         }
     }
