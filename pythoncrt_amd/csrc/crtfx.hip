@@ -266,7 +266,7 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
            ko.blend == CRTFX_BLEND_NONE;
 }
 
-constexpr int CC_MIN_RADIUS = 7;
+constexpr int CC_MIN_RADIUS = 8;
 bool use_cc(const crtfx_ctx* c, int R) {
     return c->pix_fmt == CRTFX_PIX_U8 && (c->force_cc || R >= CC_MIN_RADIUS) && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
 }
@@ -286,8 +286,8 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
     for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     // the column-owner kernel takes the full-chain launches that park a pre-warp image (warp and / or persistence behind them)
-    // — for uint8 frames and radii >= CC_MIN_RADIUS, where it is the faster build (4K, R = 9: 135 vs 140 us per 2-frame launch;
-    // 1080p, R = 4: 65 vs 61.5; 8K half frames: 288 vs 284: profiles/r02_cc_ab.txt).  Its stores address a frame's scratch
+    // — for uint8 frames and radii >= CC_MIN_RADIUS, where it is the faster build (4K, R = 9: 134 vs 140 us per 2-frame launch;
+    // R = 5 / 6 / 7 within 1-3 % the other way; 1080p, R = 4: 64 vs 60; 8K half frames: 288 vs 284: profiles/r02_cc_ab.txt).  Its stores address a frame's scratch
     // image with 32-bit byte offsets.
     bool cc = folded && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
@@ -766,7 +766,12 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (f && f->glitch_offs_dev) break;
                 KFrame kf = make_kframe(frame_in(i + g), f);
                 KOut k1{};
-                if (two) { k1.pre = c->pre + ((size_t)slot * c->group_max + g) * frame_elems; k1.pix = c->pix_fmt; } else k1 = final_out(i + g);
+                if (two) {
+                    k1.pre = c->pre + ((size_t)slot * c->group_max + g) * frame_elems; k1.pix = c->pix_fmt;
+#ifdef CC_EXP_FUSEWARP
+                    k1.out_u8 = final_out(i + g).out_u8;      // timing experiment: the phosphor kernel also writes (wrong) frames
+#endif
+                } else k1 = final_out(i + g);
                 k1.dbg = c->dbg;
                 if (!lean_ok(c, kf, k1)) break;
                 kg.f[g] = kf; kg.o[g] = k1;
@@ -780,7 +785,11 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (ovl && c->ev_k2_pending[slot]) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[slot], 0));   // slot free again
                 launch_rr_group(c, kg, g, s);
                 if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k1[slot], s)); HIP_TRY(c, hipStreamWaitEvent(sw, c->ev_k1[slot], 0)); }
+#ifdef CC_EXP_FUSEWARP
+                if (false) {
+#else
                 if (two) {
+#endif
                     const float* pre0 = c->pre + (size_t)slot * c->group_max * frame_elems;
                     if (!blend_on) {
                         KWarpGroup wg{};
