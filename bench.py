@@ -127,7 +127,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[N-1]; 0 = the reference CLI's default flags at 1080p")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 256 at 4K, 1536 at 1080p, 64 at 8K — sized so that 20 steps run >= 0.5 s)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 320 at 4K, 1536 at 1080p, 64 at 8K — sized so that 20 steps run >= 0.5 s)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of K steps after the reported one (spread only; 0 = none)")
@@ -198,7 +198,7 @@ def main():
     # frames per step: enough that the default 20 steps run >= 0.5 s (4K: 256 frames = 6.4 GB in + 6.4 GB out of the
     # 288 GB; the sharded-persistence config needs B >= settle_frames(p) anyway, see shard.py)
     from pythoncrt_amd.shard import choose_chunk
-    B = a.batch or (64 if h >= 4320 else 256 if h >= 2160 else 1536)
+    B = a.batch or (64 if h >= 4320 else 320 if h >= 2160 else 1536)
     if p > 0.0 and not a.batch:
         # sharded persistence: a chunk covers the IIR's settling time, so every round is ONE parallel hop (shard.py);
         # 512 frames (2 slots x 512 x 24.9 MB of per-frame states at 1080p) also keeps 20 steps above 0.3 s

@@ -28,10 +28,14 @@ for s in a.sigmas:
         ov = make_text_overlay_rgba(a.w, a.h, "PythonCRT on MI355X", "", 96, "#FFCC00", (64, 64))
     pipe = FramePipeline(dev, a.h, a.w, rs, fps=30.0, noise_seed=1, text_overlay_rgba=ov, text_overlay_after=(a.overlay == "after"))
     out = torch.empty_like(frames)
-    pipe.run(frames, out=out); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):      # per-frame tables (and device-generated scanline planes) are part of the timed loop here
-        pipe.run(frames, first_index=i * a.batch, out=out)
+    for _ in range(2):
+        pipe.run(frames, out=out)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f"sigma {s:5.2f}  radius {max(1, int(round(s * 3)) * 2 + 1) // 2:3d}  {a.batch * a.steps / dt:9.1f} frames/s  {dt / (a.batch * a.steps) * 1e6:8.1f} us/frame", flush=True)
+    ts = []
+    for i in range(a.steps):      # per-frame tables (and device-generated scanline planes) are part of the timed loop here
+        t0 = time.perf_counter()
+        pipe.run(frames, first_index=i * a.batch, out=out)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]      # median step: a first-touch / clock-ramp outlier does not decide a row
+    print(f"sigma {s:5.2f}  radius {max(1, int(round(s * 3)) * 2 + 1) // 2:3d}  {a.batch / dt:9.1f} frames/s  {dt / a.batch * 1e6:8.1f} us/frame  (max step {max(ts) / a.batch * 1e6:8.1f})", flush=True)
