@@ -164,7 +164,9 @@ def main_sharded(a, rank: int, world: int) -> int:
     frame_bytes = h * w * 3
     n_frames = os.path.getsize(a.input) // frame_bytes
     shard = FrameShard(world, rank, B)
-    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B), dist=dist)
+    # overlapped schedule where the chunk covers the IIR's settling time (shard.py): round r's state frame travels while round
+    # r+1 is scanned, results come back one call late; any other case runs the synchronous protocol behind the same calls
+    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=2), dist=dist, overlap=True)
     if rank == 0:
         with open(a.output, "wb") as f:
             f.truncate(n_frames * frame_bytes)
@@ -173,10 +175,26 @@ def main_sharded(a, rank: int, world: int) -> int:
     fin, fout = os.open(a.input, os.O_RDONLY), os.open(a.output, os.O_WRONLY)
     host = torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory()
     done = 0
+
+    def commit(finished):
+        nonlocal done
+        for rr, out in finished:
+            flo, fhi = shard.frame_range(rr, n_frames)
+            view = memoryview(out.cpu().numpy()).cast("B")
+            pos = 0
+            while pos < len(view):                       # os.pwrite may write less than asked (batches over 2 GiB)
+                k = os.pwrite(fout, view[pos:], flo * frame_bytes + pos)
+                if k <= 0:
+                    raise SystemExit(f"short write at frame {flo}")
+                pos += k
+            done += fhi - flo
+
+    uploaded = torch.cuda.Event()
     for r in range(shard.rounds(n_frames)):
         lo, hi = shard.frame_range(r, n_frames)
         frames = None
         if hi > lo:
+            uploaded.synchronize()                        # the previous chunk has left the pinned staging buffer
             view = memoryview(host.numpy()).cast("B")[: (hi - lo) * frame_bytes]
             got = 0
             while got < len(view):
@@ -185,11 +203,9 @@ def main_sharded(a, rank: int, world: int) -> int:
                     raise SystemExit(f"short read at frame {lo}")
                 got += k
             frames = host[: hi - lo].to(dev, non_blocking=True)
-        out = render.run_round(frames, r, active=shard.active_ranks(r, n_frames))
-        if out is not None:
-            buf = out.cpu().numpy().tobytes()
-            os.pwrite(fout, buf, lo * frame_bytes)
-            done += hi - lo
+            uploaded.record()
+        commit(render.submit_round(frames, r, active=shard.active_ranks(r, n_frames)))
+    commit(render.flush())
     os.close(fin); os.close(fout)
     dist.barrier()
     print(f"rank {rank}: {done} of {n_frames} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)
