@@ -951,6 +951,20 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
 #define CRTFX_RR_WAVES 3     // min waves per SIMD the register allocator must leave room for (4 forces spills)
 #endif
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc.x += w.h * tp.lo', acc.y += w.h * tp.hi'  with ONE v_pk_fma_f32: h = low / high half of the VGPR pair w (broadcast to
+// both lanes of the packed op through op_sel), (lo', hi') = the SGPR pair tp as it is or swapped.  The separable blur's
+// 2 x (2R + 1) x 3 fused multiply-adds per pixel are 34 % of the kernel's VALU time (tools/isa_cost.py); one input
+// feeds two neighbouring outputs with two neighbouring taps, which is exactly this instruction: measured 3.4 cycles
+// against 2 x 2.4 for two v_fmac_f32 with an SGPR tap (profiles/r02_valu_cost.txt).  Each accumulator still receives
+// its taps in the oracle's order (left to right / top to bottom), each product fused: the same bits.
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 w, bool whigh, unsigned long long tp, bool swap) {
+    if (!whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else if (!whigh && swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else if (whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
+}
+
 constexpr int RR_THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) volatile f32x4 lds_cv_f32x4;   // LDS-space, so the read stays a ds_ op
@@ -1076,9 +1090,34 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     // so only R+1 of them are ever read: 10 SGPRs instead of 19 live through both blur phases
     const float* taps = P.taps;
 #define TAP(k) taps[(k) <= R ? (k) : 2 * R - (k)]
-    float win[L];
+    // V-pass register window as L / 2 VGPR pairs (2R + NB is even): element i = win2[i >> 1], half i & 1.  One window element
+    // feeds two neighbouring output rows with two neighbouring taps = one v_pk_fma_f32 (3.4 cycles against 2 x 2.4 for two
+    // v_fmac_f32 with an SGPR tap, profiles/r02_valu_cost.txt); every output still takes its taps top to bottom, fused.
+    f32x2 win2[L / 2];
 #pragma unroll
-    for (int i = 0; i < L; ++i) win[i] = 0.0f;
+    for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
+    unsigned long long tpv[R + 1];                   // aligned SGPR pairs (tap[2m], tap[2m+1]); see k_phosphor_cc
+#pragma unroll
+    for (int m = 0; m <= R; ++m)
+        tpv[m] = (unsigned long long)__float_as_uint(taps[2 * m]) | ((unsigned long long)(2 * m + 1 <= 2 * R ? __float_as_uint(taps[2 * m + 1]) : 0u) << 32);
+    auto v_pass = [&](float* hcol) {                 // append the tile's NB rows, write the NB blurred rows in their place
+#pragma unroll
+        for (int j = 0; j < NB; ++j) win2[(2 * R + j) >> 1][j & 1] = hcol[j * 3 * TW];
+        f32x2 acc[NB / 2];
+#pragma unroll
+        for (int jp = 0; jp < NB / 2; ++jp) acc[jp] = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int jp = 0; jp < NB / 2; ++jp) {
+                const int t = i - 2 * jp;
+                if (t == 0) acc[jp].x = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].x);
+                else if (t >= 1 && t <= 2 * R) pk_fma_bcast(acc[jp], win2[i >> 1], (i & 1) != 0, (t & 1) ? tpv[(t - 1) / 2] : tpv[(2 * R - t) / 2], (t & 1) != 0);
+                else if (t == 2 * R + 1) acc[jp].y = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].y);       // tap[2R] == tap[0]
+            }
+#pragma unroll
+        for (int jp = 0; jp < NB / 2; ++jp) { hcol[(2 * jp) * 3 * TW] = acc[jp].x; hcol[(2 * jp + 1) * 3 * TW] = acc[jp].y; }
+    };
     const int hcol_off = min(wave, 2) * TW + lane;   // this thread's column in its channel plane
 #ifdef CRTFX_STAMP
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
@@ -1220,18 +1259,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         float* ht = hrow + t * HT;
         // ---- C1(n-1): vertical pass on the register window; row j = blur of output row hb-NB-R+j ----
         if (hb > y_begin - R && wave < 3) {
-            float* hcol = hrow + (t ^ 1) * HT + hcol_off;
+            v_pass(hrow + (t ^ 1) * HT + hcol_off);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
-                hcol[j * 3 * TW] = acc;
-            }
-#pragma unroll
-            for (int i = 0; i < 2 * R; ++i) win[i] = win[i + NB];
+            for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
         }
         STAMP(4);
         // ---- A(n): grade the prefetched halo rows [hb, hb+nrows) into the staging tile ----------
@@ -1313,16 +1343,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         const int hb_last = y_begin - R + ((y_end + R - (y_begin - R) - 1) / NB) * NB;
         float* htl = hrow + (t ^ 1) * HT;
         if (wave < 3) {
-            float* hcol = htl + hcol_off;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) win[2 * R + j] = hcol[j * 3 * TW];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc = fmaf(win[j + k], TAP(k), acc);
-                hcol[j * 3 * TW] = acc;
-            }
+            v_pass(htl + hcol_off);
         }
         __syncthreads();
         if (plane_scan) { sp_c2[0] = sp_next[0]; sp_c2[1] = sp_next[1]; }
@@ -1368,20 +1389,6 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 #define LDS_AT(T, off) (*(T*)(uintptr_t)(uint32_t)(off))
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// acc.x += w.h * tp.lo', acc.y += w.h * tp.hi'  with ONE v_pk_fma_f32: h = low / high half of the VGPR pair w (broadcast to
-// both lanes of the packed op through op_sel), (lo', hi') = the SGPR pair tp as it is or swapped.  The separable blur's
-// 2 x (2R + 1) x 3 fused multiply-adds per pixel are 34 % of the kernel's VALU time (tools/isa_cost.py); one input
-// feeds two neighbouring outputs with two neighbouring taps, which is exactly this instruction: measured 3.4 cycles
-// against 2 x 2.4 for two v_fmac_f32 with an SGPR tap (profiles/r02_valu_cost.txt).  Each accumulator still receives
-// its taps in the oracle's order (left to right / top to bottom), each product fused: the same bits.
-__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 w, bool whigh, unsigned long long tp, bool swap) {
-    if (!whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
-    else if (!whigh && swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
-    else if (whigh && !swap) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(tp));
-    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(tp));
-}
 
 // staging plane stride: >= the staged width and == 4 (mod 8) dwords, so that the two (row, channel) planes one 16-lane
 // ds_read_b128 group covers in the H pass (8 lanes each, 32 bytes apart) land on disjoint banks
@@ -1444,7 +1451,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     constexpr int A3 = CC_A3(NA);                        // ... of the helper wave (the last A3 items)
     constexpr int AO = (NA - A3 + 2) / 3;                // ... of each consumer wave (items wave, wave + 3, ...)
     constexpr int HT = NB * CC_HROW;
-    constexpr bool NLUT = PIX == 0;
+    constexpr bool NLUT = PIX == 0;       // a1 from the LDS table; as arithmetic (v_cvt_f32_ubyte + corrected reciprocal) it is the same speed: 135.5 vs 136.1 us
     // LDS map, byte offsets from 0 (LDS_AT): every hot access is `constant + per-lane offset`, so that the constant rides in the
     // instruction's immediate and the per-lane part is one shift or add
     constexpr uint32_t STG_B = 0;                                            // [NB][3][SWS] float      staging tile
@@ -1452,7 +1459,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   triad LUT pair
     constexpr uint32_t CRING_B = LUT_B + 2 * LUT_STRIDE * 4;                 // uint8: [CR][TW] packed dwords; half: [CR][TW][3] uint16   parked centre samples
     constexpr uint32_t NLUT_B = CRING_B + cc_cring_words(R, PIX) * 4;        // [256] float             u / 255.0 (uint8 frames)
-    constexpr uint32_t GVIG_B = NLUT_B + (NLUT ? 256 * 4 : 0);               // [NB][TW] double         vignette gain tile
+    constexpr uint32_t GVIG_B = NLUT_B + (PIX == 0 ? 256 * 4 : 0);           // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
     constexpr uint32_t ROWTAB_B = GN_B + 2 * NB * TW * 4;                    // [16][4] uint32          scan gain bits, ny2 lo, ny2 hi, -
     constexpr uint32_t WRING_B = ROWTAB_B + 16 * 4 * 4;                      // CC_EXP_FUSEWARP only: [2][NB][TW][3] float
@@ -1666,7 +1673,8 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 int cr = c2row0 + j;
                 cr = cr >= CR ? cr - CR : cr;
                 if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
-                else v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
+                else if constexpr (NLUT) v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
+                else v[j] = norm_u8((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl));
             }
             float blur[NB];
             v_pass(blur);
@@ -1738,7 +1746,8 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 int cr = c2row0 + j;
                 cr = cr >= CR ? cr - CR : cr;
                 if constexpr (PIX) v[j] = norm_px(PIX, (uint32_t)cring16[cr * 3 * TW + f]);
-                else v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
+                else if constexpr (NLUT) v[j] = LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl) << 2));
+                else v[j] = norm_u8((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl));
             }
             v_pass(blur);
             __syncthreads();
