@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CRTFX_LIB") or os.path.join(_HERE, "libcrtfx.so")   #
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("crtfx.hip", "crtfx_rr.hip", "crtfx_kernels.hip.h", "crtfx_internal.h")] + \
           [os.path.join(ROOT, "include", "crtfx.h")]
-RR_RADII = tuple(range(1, 31)) + (36, 42, 48, 64, 80, 96, 112, 128)      # one build per radius up to 30, then radius buckets (crtfx_internal.h)
+RR_RADII = tuple(range(1, 31))      # one register-window build per radius up to 30 (crtfx_internal.h); larger radii: the split path
 
 OK, E_INVALID, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4
 PIX_U8, PIX_F16 = 0, 1

@@ -26,6 +26,11 @@ struct DevBuf {
 
 }  // namespace
 
+// Gaussian bloom radii from here on run the split path (three blur kernels + the pointwise chain) instead of a fused
+// register-window build: see k_sb_rows in crtfx_kernels.hip.h and profiles/r02_sigma_sweep.txt for the crossover.
+constexpr int SPLIT_FROM_RADIUS = 31;
+constexpr int SPLIT_MAX_RADIUS = 1 << 16;     // sigma ~ 21845: far beyond any frame size; a sanity bound on the tap array only
+
 struct crtfx_ctx {
     int device = 0;
     int H = 0, W = 0;
@@ -33,7 +38,12 @@ struct crtfx_ctx {
     bool params_set = false;
     KParams kp{};
     DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts;
-    DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch
+    DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch (split bloom: two full-res planes)
+    DevBuf tpad;                     // split bloom: zero-padded taps (sb_tpad_len)
+    bool split = false;              // this parameter set runs the Gaussian bloom as k_sb_src / k_sb_rows / k_sb_cols + the pointwise kernels
+    int split_R = 0;                 // its radius (kp.R is 0 then)
+    bool split_src_plane = false;    // CRTFX_OPT_SPLIT_SRC_PLANE
+    int split_from = SPLIT_FROM_RADIUS;   // CRTFX_OPT_SPLIT_FROM: radii >= this take the split path (0 = every radius)
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
@@ -262,7 +272,7 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
     // (text overlays before the effects, or after them when the same kernel also commits) are handled by the runtime-gate build only
     const bool needs_runtime = kf.scan_plane || ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) || kf.overlay_before || ko.overlay_after;
     (void)folded; (void)needs_runtime;      // both pixel formats have a gate-folded and a runtime-gate build
-    return !c->force_generic && rr_build_radius(R) == R && R >= 1 && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
+    return !c->force_generic && !c->split && rr_build_radius(R) == R && R >= 1 && !c->kp.triad_full && !c->kp.vig_full && !kf.noise_plane &&
            ko.blend == CRTFX_BLEND_NONE;
 }
 
@@ -362,6 +372,30 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
     CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, identity ? 1 : 0);
 }
 
+// Split Gaussian bloom: P.ds (plane A) <- blur of the frame's bloom source; plane B is the row-pass intermediate.
+void launch_split_blur(crtfx_ctx* c, const KFrame& kf, hipStream_t s) {
+    const int H = c->H, W = c->W, R = c->split_R;
+    float* A = (float*)c->ds.p;
+    float* B = A + (size_t)H * W * 3;
+    const unsigned long long* tp = (const unsigned long long*)c->tpad.p;
+    const int npairs = sb_tpad_len(R) / 2;
+    const dim3 gr((W + SB_SPAN - 1) / SB_SPAN, (H + SB_RW - 1) / SB_RW), br(64 * SB_RW);
+    if (c->split_src_plane) {      // CRTFX_OPT_SPLIT_SRC_PLANE (A/B): the bloom source as its own plane first
+        dim3 gs((W + 63) / 64, (H + 3) / 4);
+        if (c->pix_fmt == CRTFX_PIX_F16) hipLaunchKernelGGL((k_sb_src<CRTFX_PIX_F16>), gs, dim3(256), 0, s, c->kp, kf);
+        else hipLaunchKernelGGL((k_sb_src<CRTFX_PIX_U8>), gs, dim3(256), 0, s, c->kp, kf);
+        hipLaunchKernelGGL((k_sb_rows<-1>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
+    } else if (c->pix_fmt == CRTFX_PIX_F16) hipLaunchKernelGGL((k_sb_rows<CRTFX_PIX_F16>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
+    else hipLaunchKernelGGL((k_sb_rows<CRTFX_PIX_U8>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
+    const int rowlen = 3 * W;
+    if ((W & 3) == 0 && !c->split_src_plane) {
+        const int nbx = (rowlen + 255) / 256, nby = (H + SBC_W * SB_N - 1) / (SBC_W * SB_N);
+        hipLaunchKernelGGL(k_sb_cols_lds, dim3(8 * ((nbx * nby + 7) / 8)), dim3(64 * SBC_W), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs, nbx, nby);
+    }
+    else if ((W & 3) == 0) hipLaunchKernelGGL((k_sb_cols<4>), dim3((rowlen + 255) / 256, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs);
+    else hipLaunchKernelGGL((k_sb_cols<1>), dim3((rowlen + 63) / 64, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs);
+}
+
 // The whole chain for one frame.  ko describes the FINAL outputs.
 int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipStream_t s) {
     ko.pix = c->pix_fmt;
@@ -373,7 +407,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         return fail(c, CRTFX_E_INVALID, "scanlines are on but the frame record carries no scan_row_dev / scan_plane_dev");
     const KFrame kf = make_kframe(in, f);
     const bool warp = (fl & CRTFX_F_WARP) != 0;
-    const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);
+    const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST) && !c->split;
     const bool ov_after = f && f->overlay_rgba_dev && f->overlay_after;
     const bool glitch = f && f->glitch_offs_dev;
     if (glitch && f->glitch_seg_len < 0) return fail(c, CRTFX_E_INVALID, "glitch_seg_len is negative");
@@ -386,18 +420,17 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
     // behind the Gaussian bloom kernel (kept lean; the state is float32 anyway).  An overlay-after with
     // no warp stays in ONE kernel (the general-purpose build), so that it blends the unrounded image
     // exactly as ref:653-662 does.
-    const bool two = warp || glitch || (gauss && ko.blend != CRTFX_BLEND_NONE);
+    const bool two = warp || glitch || ((gauss || c->split) && ko.blend != CRTFX_BLEND_NONE);
     if (ov_after) ko.overlay_after = f->overlay_rgba_dev;
     if (glitch) { ko.glitch_offs = f->glitch_offs_dev; ko.glitch_y0 = f->glitch_y0; ko.glitch_cols = f->glitch_cols; ko.glitch_seg_len = f->glitch_seg_len; }
     KOut k1 = ko;
     if (two) { k1 = KOut{}; k1.pre = c->pre; }
     k1.dbg = c->dbg;
     if (gauss) {
-        if (!lean_ok(c, kf, k1) && c->kp.R > GENERIC_MAX_RADIUS)
-            return fail(c, CRTFX_E_UNSUPPORTED, "injected per-pixel planes / an in-kernel blend go through the LDS-ring kernel, which stops at bloom radius %d (asked: a build radius of %d)", GENERIC_MAX_RADIUS, c->kp.R);
         launch_phosphor(c, kf, k1, s);
     } else {
-        if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
+        if (c->split) launch_split_blur(c, kf, s);      // Gaussian bloom of any radius: the blurred plane first
+        else if (fl & CRTFX_F_BLOOM) {   // fast bloom: half-res source first
             dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4);
             const uint32_t g0 = fl & ~(uint32_t)CRTFX_F_WARP;
             const bool fold = !c->force_generic && !c->force_runtime_flags && (g0 == SF_FAST || g0 == SF_FAST_PIX) && !kf.overlay_before;
@@ -506,10 +539,8 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         if (!(p->fbu_xofs && p->fbu_xw && p->fbu_yofs && p->fbu_yw)) return fail(c, CRTFX_E_INVALID, "fast bloom needs the fbu_* upsample axes");
         if ((p->fbd_xofs != nullptr) != (p->fbd_yofs != nullptr) || (p->fbd_xofs && !(p->fbd_xw && p->fbd_yw))) return fail(c, CRTFX_E_INVALID, "fbd_* axes must be given together");
     } else if (fl & CRTFX_F_BLOOM) {
-        if (p->bloom_radius < 0 || p->bloom_radius > MAX_RADIUS)
-            return fail(c, CRTFX_E_UNSUPPORTED, "bloom radius %d outside [0,%d] (sigma up to ~42.8)", p->bloom_radius, MAX_RADIUS);
-        if (c->force_generic && p->bloom_radius > GENERIC_MAX_RADIUS)
-            return fail(c, CRTFX_E_UNSUPPORTED, "the LDS-ring kernel stops at bloom radius %d", GENERIC_MAX_RADIUS);
+        if (p->bloom_radius < 0 || p->bloom_radius > SPLIT_MAX_RADIUS)
+            return fail(c, CRTFX_E_INVALID, "bloom radius %d outside [0,%d]", p->bloom_radius, SPLIT_MAX_RADIUS);
         if (!p->bloom_taps) return fail(c, CRTFX_E_INVALID, "bloom on but bloom_taps NULL");
     }
     if ((fl & CRTFX_F_TRIAD) && !p->triad_row && !p->triad_full_dev) return fail(c, CRTFX_E_INVALID, "triad on but no mask");
@@ -522,10 +553,15 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     int rc;
     const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
     const int R_asked = ((fl & CRTFX_F_BLOOM) && !fastb) ? p->bloom_radius : 0;
-    // radii beyond the per-radius builds run the next bucket's build on zero-padded taps (crtfx_internal.h); injected
-    // per-pixel planes / FORCE_GENERIC take the LDS-ring kernel at the radius asked for (<= GENERIC_MAX_RADIUS)
+    // injected per-pixel planes / FORCE_GENERIC take the LDS-ring kernel (radii <= GENERIC_MAX_RADIUS, and only below split_from)
     const bool ring_only = c->force_generic || p->triad_full_dev || p->vignette_full_dev;
-    const int R = (R_asked > RR_MAX_RADIUS && !(ring_only && R_asked <= GENERIC_MAX_RADIUS)) ? rr_build_radius(R_asked) : R_asked;
+    // ... and every radius from split_from on (or past what those kernels are built for) runs the split path: blur
+    // kernels with no radius limit + the pointwise chain; the fused kernels then see no bloom radius at all
+    const bool split = (fl & CRTFX_F_BLOOM) && !fastb &&
+                       (R_asked >= c->split_from || R_asked > GENERIC_MAX_RADIUS || (R_asked > RR_MAX_RADIUS && !ring_only));
+    const int R = split ? 0 : R_asked;       // <= RR_MAX_RADIUS: a register-window build or the LDS-ring kernel; up to GENERIC_MAX_RADIUS: the latter only
+    c->split = split;
+    c->split_R = R_asked;
     const bool grain_up = (fl & CRTFX_F_NOISE) && p->grain_size > 1;
     if (grain_up && !(p->grain_xofs && p->grain_xw && p->grain_yofs && p->grain_yw && p->grain_w >= 1 && p->grain_h >= 1))
         return fail(c, CRTFX_E_INVALID, "grain_size > 1 needs the grain_* resize axes");
@@ -560,6 +596,19 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
             c->ds.bytes = need;
         }
     }
+    if (split) {
+        const size_t need = (size_t)2 * H * W * 3 * sizeof(float);      // plane A (source, then the blur) and plane B (row pass)
+        if (c->ds.bytes < need) {
+            free_buf(c->ds);
+            HIP_TRY(c, hipMalloc(&c->ds.p, need));
+            c->ds.bytes = need;
+        }
+        const size_t L = (size_t)sb_tpad_len(R_asked);      // [tpad | tpadB]: tpadB = tpad moved down one float, so that both the
+        std::vector<float> tp(2 * L, 0.0f);                 // even and the odd tap pairs are aligned 64-bit scalar loads
+        std::memcpy(tp.data() + (SB_N - 1), p->bloom_taps, (2 * (size_t)R_asked + 1) * sizeof(float));
+        std::memcpy(tp.data() + L + (SB_N - 2), p->bloom_taps, (2 * (size_t)R_asked + 1) * sizeof(float));
+        if ((rc = upload(c, c->tpad, tp.data(), tp.size() * sizeof(float)))) return rc;
+    }
 
     KParams k{};
     k.H = H; k.W = W; k.pix = c->pix_fmt; k.flags = fl & 0xFFFFu; k.ab = p->aberration_px; k.R = R; k.grain = p->grain_size;
@@ -568,9 +617,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.thr = p->bloom_thr; k.thr_den = p->bloom_thr_den; k.bloom_strength = p->bloom_strength;
     k.noise_scale = p->noise_scale; k.warp_k = p->warp_k; k.cx = p->warp_cx; k.cy = p->warp_cy;
     k.vig_strength = p->vignette_strength;
-    if ((fl & CRTFX_F_BLOOM) && !fastb) {
+    if ((fl & CRTFX_F_BLOOM) && !fastb && !split) {
         std::memset(k.taps, 0, sizeof k.taps);
-        std::memcpy(k.taps + (R - R_asked), p->bloom_taps, (2 * R_asked + 1) * sizeof(float));      // centred in the build's 2R + 1 taps
+        std::memcpy(k.taps, p->bloom_taps, (2 * R + 1) * sizeof(float));
     }
     k.triad_row = p->triad_row ? (const float*)c->triad_row.p : nullptr;
     k.triad_full = p->triad_full_dev;
@@ -897,6 +946,8 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
+    case CRTFX_OPT_SPLIT_SRC_PLANE: c->split_src_plane = value != 0; break;
+    case CRTFX_OPT_SPLIT_FROM: if (value < 0) return fail(c, CRTFX_E_INVALID, "split_from %d < 0", value); c->split_from = value; break;
     case CRTFX_OPT_GROUP: if (value < 0 || value > MAX_GROUP) return fail(c, CRTFX_E_INVALID, "group %d outside 0..%d", value, MAX_GROUP); c->opt_group = value; break;
     case CRTFX_OPT_SEG_ROWS: if (value < 0) return fail(c, CRTFX_E_INVALID, "seg_rows %d < 0", value); c->opt_seg_rows = value ? ((value + NB - 1) / NB) * NB : 0; break;
     case CRTFX_OPT_WARP_ROWS: if (value != 1 && value != 2 && value != 4) return fail(c, CRTFX_E_INVALID, "warp rows must be 1, 2 or 4"); c->warp_rows = value; break;

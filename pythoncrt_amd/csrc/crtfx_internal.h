@@ -13,21 +13,16 @@ using rr_launch_fn = void (*)(const KParams&, const KGroup&, int seg_rows, dim3 
                               hipEvent_t ev_start, hipEvent_t ev_stop);
 
 #define CRTFX_RR_RADII(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) \
-                          X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(36) X(42) X(48) X(64) X(80) X(96) X(112) X(128)
+                          X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
 #define CRTFX_RR_DECL(r) void rr_launch_##r(const KParams&, const KGroup&, int, dim3, size_t, hipStream_t, int, hipEvent_t, hipEvent_t);
 CRTFX_RR_RADII(CRTFX_RR_DECL)
 #undef CRTFX_RR_DECL
 
 constexpr int RR_MAX_RADIUS = 30;      // one build per radius up to here: bloom sigma <= 10, the reference GUI's range (ref:1475)
-// Larger radii (the reference accepts any sigma, ref:609-610, :1231) run the build of the next BUCKET radius with the
-// taps zero-padded symmetrically to its length: fma(x, 0, acc) == acc for the finite samples of a uint8 frame, so the sums
-// and their order are unchanged — bit-exact — at the cost of the bucket's tap count (<= 1.5 x the radius asked for).
-constexpr int RR_BUCKETS[] = {36, 42, 48, 64, 80, 96, 112, 128};
-inline int rr_build_radius(int R) {     // the compiled radius that serves bloom radius R (0 = none: R = 0 or beyond the largest bucket)
-    if (R >= 1 && R <= RR_MAX_RADIUS) return R;
-    for (int b : RR_BUCKETS) if (R <= b) return R >= 1 ? b : 0;
-    return 0;
-}
+// Larger radii (the reference accepts any sigma, ref:609-610, :1231) run the split path (k_sb_rows / k_sb_cols + the
+// pointwise chain, crtfx.hip launch_split_blur).  (Round 2 first served 31..128 with "bucket" builds of this kernel at
+// R = 36 .. 128 on zero-padded taps: bit-exact too, but 380 us -> 29 ms per 4K frame against the split path's 344 -> 640.)
+inline int rr_build_radius(int R) { return (R >= 1 && R <= RR_MAX_RADIUS) ? R : 0; }     // the compiled radius that serves bloom radius R (0 = none)
 
 // Launch with optional timing events attached to the dispatch packet itself (hipExtLaunchKernelGGL):
 // no extra packets on the stream.  Separate hipEventRecord calls around every kernel cost ~5 us of

@@ -150,14 +150,35 @@ def test_scanlines_2d_and_vignette_array(pc):
 
 
 @pytest.mark.parametrize("hw", SIZES + [(150, 64)])
-@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 4.4, 6.5, 8.3, 10.0, 12.0, 20.0, 27.0, 40.0])       # radii 9 4 2 1 12 | 13 20 25 30 (one build each) | 36 60 81 120 (buckets 48 64 96 128)
+@pytest.mark.parametrize("sigma", [3.0, 1.2, 0.5, 0.1, 4.0, 4.4, 6.5, 8.3, 10.0, 12.0, 20.0, 27.0, 40.0, 50.0, 85.0])       # radii 9 4 2 1 12 | 13 20 25 30 (one build each) | 36 60 81 120 150 255 (split path)
 def test_bloom_bit_exact(pc, hw, sigma):
     """a5: separable Gaussian (LDS strips, H pass, register-window V pass) — same fmaf accumulation order as the
-    oracle, so equal to the last bit, borders included.  Radii beyond 30 run the next bucket's build on zero-padded
-    taps (crtfx_internal.h): still the same sums — the reference takes any sigma (ref:609-610)."""
+    oracle, so equal to the last bit, borders included.  Radii beyond 30 run the split path (k_sb_rows / k_sb_cols,
+    taps from a device array): the same sums at ANY radius, here up to several times the frame size — the reference
+    takes any sigma (ref:609-610)."""
     frame = make_frame(*hw, seed=9)
     got, exp = run_both(pc, frame, dict(bloom_sigma=sigma, bloom_strength=0.25, aberration_px=1))
     assert_bit_exact(got, exp)
+
+
+@pytest.mark.parametrize("hw", [(70, 130), (33, 1030), (9, 200), (1, 1), (3, 5)])
+@pytest.mark.parametrize("sigma", [0.5, 3.0, 11.0, 60.0])
+def test_split_bloom_any_radius(pc, hw, sigma, monkeypatch):
+    """The split path forced for EVERY radius (SPLIT_FROM = 0), full chain with and without the warp, frame widths not a
+    multiple of 4 (scalar column pass), rows longer than one 512-px span and a chunked row pass (radius 180 > 256 / 2 steps)."""
+    from pythoncrt_amd import effects
+    monkeypatch.setattr(effects, "DEBUG_OPTIONS", {"SPLIT_FROM": 0})
+    effects._tls.engines = {}
+    try:
+        h, w = hw
+        frame = make_frame(h, w, seed=14, kind="grad")
+        plane = np.random.default_rng(14).standard_normal((h, w), dtype=np.float32)
+        got, exp = run_both(pc, frame, dict(FULL, bloom_sigma=sigma, bloom_threshold=0.2), noise_plane=plane)
+        assert_bit_exact(got, exp)
+        got, exp = run_both(pc, frame, dict(FULL, bloom_sigma=sigma), noise_plane=plane, warp_strength=0.15)
+        assert np.abs(got.astype(np.float64) - exp).max() <= 3e-7
+    finally:
+        effects._tls.engines = {}
 
 
 @pytest.mark.parametrize("sigma", [1.2, 3.0])        # BASELINE configs 2 and 3
@@ -339,9 +360,10 @@ def test_errors_are_loud(pc):
         pc.apply_static_effects(frame, 0.0, pc.make_triad_mask(10, 10, 0.3), *a[3:])
     with pytest.raises(ValueError):
         pc.apply_static_effects(*a, text_overlay_rgba=np.zeros((10, 10, 3), np.uint8))       # RGBA plane wanted
-    pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                            # sigma 40 -> radius 120: runs (bucket 128)
+    pc.apply_static_effects(*a[:6], 40.0, *a[7:])                                            # sigma 40 -> radius 120: runs
+    pc.apply_static_effects(*a[:6], 500.0, *a[7:])                                           # sigma 500 -> radius 1500 (31x the frame): runs too
     with pytest.raises(Exception, match="radius"):
-        pc.apply_static_effects(*a[:6], 50.0, *a[7:])                                        # sigma 50 -> radius 150 > 128
+        pc.apply_static_effects(*a[:6], 30000.0, *a[7:])                                     # radius 90000: past the tap array's sanity bound
 
 
 # ---- BASELINE full sizes: size-independent properties ------------------------------------------
@@ -402,7 +424,8 @@ def test_kernel_variants_agree(pc, monkeypatch):
     frame = make_frame(h, w, seed=60, kind="grad")
     tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
     outs = {}
-    for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1})):
+    for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}),
+                       ("split", {"SPLIT_FROM": 0}), ("split_plane", {"SPLIT_FROM": 0, "SPLIT_SRC_PLANE": 1})):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
@@ -426,7 +449,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(st.cpu().numpy())
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("cc", "no_cc", "runtime_flags", "generic"):
+    for name in ("cc", "no_cc", "runtime_flags", "generic", "split", "split_plane"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
 
@@ -604,7 +627,8 @@ def f16_frame(h, w, seed):
 @pytest.mark.parametrize("cfg", [dict(aberration_px=1), dict(FULL, bloom_sigma=3.0), dict(FULL, bloom_sigma=1.2, triad_preserve_luma=True),
                                  dict(FULL, bloom_sigma=6.5), dict(FULL, fast_bloom=True, pixel_size=2),
                                  dict(FULL, noise_strength=0.0, bloom_sigma=2.0, bloom_threshold=0.2),     # runtime-gate half build of k_phosphor_rr
-                                 dict(FULL, noise_strength=0.0, bloom_sigma=5.0, triad_preserve_luma=True, pixel_size=2)])
+                                 dict(FULL, noise_strength=0.0, bloom_sigma=5.0, triad_preserve_luma=True, pixel_size=2),
+                                 dict(FULL, bloom_sigma=11.0), dict(FULL, bloom_sigma=30.0, pixel_size=2, bloom_threshold=0.3)])      # radii 33, 90: the split path on half frames
 def test_fp16_frames(pc, cfg):
     """A float16 frame is the reference's frame array held as half (ref:569 divides whatever it gets by
     255.0); the float image is compared as for uint8 frames, the half output frame is |x*255| narrowed."""
@@ -813,6 +837,29 @@ def test_4k_render_loop_against_oracle(pc):
     dev = torch.device("cuda", torch.cuda.current_device())
     n, first, seed = 2, 7, 4242
     frames = np.stack([make_frame(h, w, seed=300 + i, kind="grad") for i in range(n)])
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed)
+    out, _ = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    planes = _export_planes(pipe, seed, first, n, h, w)
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma",
+                                          "bloom_strength", "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom",
+                                          "pixel_size", "warp_strength")}
+    exp, _ = orc.process_frames(list(frames), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength, noise_planes=planes, first_index=first)
+    d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3, (int(d.max()), float((d != 0).mean()))
+
+
+@pytest.mark.parametrize("sigma", [11.0, 45.0])          # radii 33, 135
+def test_render_loop_any_sigma(pc, sigma):
+    """The render loop (crtfx_process_batch: warp, persistence 0.5, in-kernel grain) with a bloom sigma beyond the GUI's
+    range — the split path behind the same entry point — against the oracle's in-order render (ref:609-610 takes any sigma)."""
+    import dataclasses
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs = dataclasses.replace(baseline_config(4)[0], bloom_sigma=sigma)
+    h, w = 120, 200
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, first, seed = 3, 5, 99
+    frames = np.stack([make_frame(h, w, seed=400 + i, kind="grad") for i in range(n)])
     pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed)
     out, _ = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
     planes = _export_planes(pipe, seed, first, n, h, w)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frames/s of the 4K (or --h/--w) full chain as a function of the bloom sigma (radius = round(3 sigma)):
-one build per radius up to 30, then the radius buckets 48 / 64 / 96 / 128 on zero-padded taps."""
+one fused build per radius up to 30, then the split bloom path (any radius)."""
 import argparse, dataclasses, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,10 @@ ap.add_argument("--h", type=int, default=2160); ap.add_argument("--w", type=int,
 ap.add_argument("--batch", type=int, default=8); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--overlay", choices=["none", "before", "after"], default="none", help="a text overlay blended before / after the effects")
 ap.add_argument("--set", nargs="*", default=[], metavar="field=value", help="RenderSettings overrides, e.g. scanline_angle=12 grain_size=2")
+ap.add_argument("--opt", nargs="*", default=[], metavar="NAME=VALUE", help="crtfx_set_option switches, e.g. SPLIT_FROM=129")
 a = ap.parse_args()
+from pythoncrt_amd import effects
+effects.DEBUG_OPTIONS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
 dev = torch.device("cuda", 0)
 frames = torch.randint(0, 256, (a.batch, a.h, a.w, 3), dtype=torch.uint8, device=dev)
 for s in a.sigmas:
