@@ -973,7 +973,9 @@ __device__ __forceinline__ void point_finish(const KParams& P, const KFrame& F, 
     }
 }
 
-template <int PIX>
+// ONE: neither pixelate nor fast bloom is on (the host checks), so no sample address waits for an index-table load and
+// both load groups issue as one: a single memory round trip per wavefront (4K split-bloom chain: 104 -> see DESIGN.md).
+template <int PIX, bool ONE = false>
 __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut Oin) {
     __shared__ float lut[2 * LUT_STRIDE];
     KParams P = Pin;
@@ -994,11 +996,15 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     const int x = min(x0 + lane, P.W - 1);         // lanes past the right edge redo the last pixel: same values, same stores
     const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
     // ---- group 1: loads whose addresses need no other load --------------------------------------------------
-    const bool pxl = (fl & CRTFX_F_PIXELATE) != 0;
-    const int xm = *(pxl ? P.xmap + x : zi), ym = *(pxl ? P.ymap + y : zi);
-    const bool fb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
-    const int ux = *(fb ? P.ux_ofs + x : zi), uy = *(fb ? P.uy_ofs + y : zi);
-    const float ua = *(fb ? P.ux_a + x : zf), ub = *(fb ? P.uy_a + y : zf);
+    const bool pxl = !ONE && (fl & CRTFX_F_PIXELATE) != 0;
+    const bool fb = !ONE && (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
+    int xm = 0, ym = 0, ux = 0, uy = 0;
+    float ua = 0.0f, ub = 0.0f;
+    if constexpr (!ONE) {
+        xm = *(pxl ? P.xmap + x : zi); ym = *(pxl ? P.ymap + y : zi);
+        ux = *(fb ? P.ux_ofs + x : zi); uy = *(fb ? P.uy_ofs + y : zi);
+        ua = *(fb ? P.ux_a + x : zf); ub = *(fb ? P.uy_a + y : zf);
+    }
     const bool tri = (fl & CRTFX_F_TRIAD) != 0;
     const F3 tm = *reinterpret_cast<const F3*>(tri ? (P.triad_full ? P.triad_full + (size_t)pix * 3 : P.triad_row + x * 3) : ones);
     const float sl = *((fl & CRTFX_F_SCANLINES) ? (F.scan_plane ? F.scan_plane + pix : F.scan_row + y) : ones);
@@ -1023,10 +1029,13 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     const int hw = fb ? P.hw : 1, hh = fb ? P.hh : 1;
     const float* dsb = fb ? P.ds : zf;
     const int ux1 = min(ux + 1, hw - 1), uy1 = min(uy + 1, hh - 1);
-    const F3 p00 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux) * 3);
-    const F3 p01 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux1) * 3);
-    const F3 p10 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux) * 3);
-    const F3 p11 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux1) * 3);
+    F3 p00{0, 0, 0}, p01{0, 0, 0}, p10{0, 0, 0}, p11{0, 0, 0};
+    if constexpr (!ONE) {
+        p00 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux) * 3);
+        p01 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux1) * 3);
+        p10 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux) * 3);
+        p11 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux1) * 3);
+    }
     __syncthreads();                               // LUTs visible (every thread of the block gets here)
     // ---- arithmetic, gated ----------------------------------------------------------------------------------------
     float r, g, b;

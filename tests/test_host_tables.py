@@ -29,6 +29,14 @@ def test_abi_exports_every_declared_symbol(lib):
     assert lib.crtfx_version() == 1
 
 
+def test_option_ids_match_the_header():
+    """effects._OPTION_IDS (the names DEBUG_OPTIONS / bench.py --opt take) == the crtfx_option enum of include/crtfx.h."""
+    from pythoncrt_amd import effects
+    hdr = open(os.path.join(ROOT, "include", "crtfx.h")).read()
+    enum = {k: int(v) for k, v in re.findall(r"CRTFX_OPT_([A-Z_]+)\s*=\s*(\d+)", hdr)}
+    assert enum and enum == effects._OPTION_IDS, set(enum.items()) ^ set(effects._OPTION_IDS.items())
+
+
 def test_struct_layout_matches_header(lib):
     """crtfx_set_params rejects a struct whose size field disagrees with the C sizeof."""
     import ctypes
