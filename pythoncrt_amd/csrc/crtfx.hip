@@ -634,7 +634,8 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
     k.grade_lut = use_glut ? (const float*)c->glut.p : nullptr;
     {
-        float cst[32] = {1.0f, 1.0f, 1.0f, 1.0f};      // then zeros: the address a disabled stage loads from in k_point_sel
+        float cst[32 + 256] = {1.0f, 1.0f, 1.0f, 1.0f};      // then zeros: the address a disabled stage loads from in k_point_sel
+        for (int i = 0; i < 256; ++i) cst[32 + i] = (float)i / 255.0f;      // u / 255 (the IEEE quotient, = norm_u8)
         if ((rc = upload(c, c->consts, cst, sizeof(cst)))) return rc;
         k.consts = (const float*)c->consts.p;
     }

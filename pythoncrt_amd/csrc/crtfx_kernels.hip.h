@@ -1296,6 +1296,28 @@ __global__ __launch_bounds__(K1_THREADS) void k_phosphor(KParams P, KFrame F, KO
 #define CRTFX_RR_WAVES 3     // min waves per SIMD the register allocator must leave room for (4 forces spills)
 #endif
 
+// Wave priorities (s_setprio) of the sections of a trip: the issue arbiter prefers the higher one when several of a SIMD's
+// waves are ready.  VH: the packed-FMA bursts (V pass, H pass); C2: the pointwise tail; A: everything else of a consumer
+// wave (LDS traffic, prefetch, barriers); HELP: the helper wave.
+#ifndef CC_P_VH
+#define CC_P_VH 2
+#endif
+#ifndef CC_P_C2
+#define CC_P_C2 1
+#endif
+#ifndef CC_P_A
+#define CC_P_A 0
+#endif
+#ifndef CC_P_HELP
+#define CC_P_HELP 0
+#endif
+#define CC_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#ifndef RR_P_VH
+#define RR_P_VH 2
+#endif
+#ifndef RR_P_C2
+#define RR_P_C2 1
+#endif
 constexpr int RR_THREADS = 256;
 typedef __attribute__((address_space(3))) volatile f32x4 lds_cv_f32x4;   // LDS-space, so the read stays a ds_ op
 
@@ -1585,9 +1607,11 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         float* ht = hrow + t * HT;
         // ---- C1(n-1): vertical pass on the register window; row j = blur of output row hb-NB-R+j ----
         if (hb > y_begin - R && wave < 3) {
+            CC_PRIO(RR_P_VH);
             v_pass(hrow + (t ^ 1) * HT + hcol_off);
 #pragma unroll
             for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
+            CC_PRIO(0);
         }
         STAMP(4);
         // ---- A(n): grade the prefetched halo rows [hb, hb+nrows) into the staging tile ----------
@@ -1629,9 +1653,11 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
         __syncthreads();
         STAMP(1);
         // ---- C2(n-1): combine + masks + store -----------------------------------------------------
+        CC_PRIO(RR_P_C2);
         if (hb > y_begin - R) phase_c2(hb - NB, hrow + (t ^ 1) * HT);
         STAMP(6);
         // ---- B(n): horizontal pass -> tile t ----------------------------------------------------------
+        CC_PRIO(RR_P_VH);
 #pragma unroll
         for (int u = 0; u < B_ITEMS; ++u) {
             const int it = tid + u * RR_THREADS;
@@ -1660,6 +1686,7 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
                 smem4[(NB * 3 * SWS + t * HT) / 4 + (j * 3 + c) * (TW / 4) + gq] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
+        CC_PRIO(0);
         STAMP(2);
         __syncthreads();
         STAMP(3);
@@ -1956,6 +1983,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         // exactly the stores in flight
 #pragma unroll
         for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b32(0u, pre_rsrc, 0xFFFFFF00u - 16u * (uint32_t)j, 0, 0);      // out of range: dropped
+        CC_PRIO(CC_P_A);
         int crow0 = 0, c2row0 = NB;
         int hb = y_begin - R;
         uint32_t off0 = fin ? (uint32_t)(y_begin - 2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R, float f), modulo 2^32 while that row is < 0
@@ -2003,12 +2031,21 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 else v[j] = norm_u8((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl));
             }
             float blur[NB];
+#ifdef CC_EXP_ANLUT_TA      // A/B: the A items' a1 lookups as L1 gathers from a global copy of the table, issued before the V pass
+            float nv[AO][3];
+#pragma unroll
+            for (int u = 0; u < AO; ++u) { nv[u][0] = P.consts[32 + raw[u].r]; nv[u][1] = P.consts[32 + raw[u].g]; nv[u][2] = P.consts[32 + raw[u].b]; }
+#endif
+            CC_PRIO(CC_P_VH);
             v_pass(blur);
+            CC_PRIO(CC_P_A);
             STAMP(4);
             {
+#ifndef CC_EXP_ANLUT_TA
                 float nv[AO][3];
 #pragma unroll
                 for (int u = 0; u < AO; ++u) a_lookup(raw[u], nv[u]);
+#endif
 #pragma unroll
                 for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u], nv[u]);
             }
@@ -2018,6 +2055,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
             __syncthreads();
             STAMP(1);
             // ---- phase 2: C2 of block n-1 (output rows hb - NB - R + j), stage by stage over the eight rows ----
+            CC_PRIO(CC_P_C2);
             const int yb = hb - NB - R;
             // the per-pixel tiles of the helper wave and the row gains first: they depend on nothing in here, and their
             // round trip then runs beside the two LUT gathers instead of behind them
@@ -2059,7 +2097,9 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 }
             }
             STAMP(6);
+            CC_PRIO(CC_P_VH);
             h_pass(wave);
+            CC_PRIO(CC_P_A);
             STAMP(2);
             __syncthreads();
             STAMP(3);
@@ -2114,6 +2154,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
             for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hbn, offr[u], offg[u], offb[u]);
         };
         prefetch(y_begin - R);
+        CC_PRIO(CC_P_HELP);
         int crow0 = 0;
         int hb = y_begin - R;
         for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB) {
@@ -2354,6 +2395,8 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
         taps[r] = warp_load_buf(P, pre_rs, ix, iy, fx, fy);
         if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
+    // (s_setprio 1 / 3 from here on — a wave whose taps have arrived drains ahead of the waves still issuing loads — measured
+    // slower: 59.2 / 60.8 vs 56.6 us per 2-frame 4K launch.)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int y = ybase + 4 * r;
