@@ -338,24 +338,24 @@ void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3
 }
 
 template <bool PROMOTE, int BLEND>
-void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int rows = c->warp_rows;      // output rows per thread
     grid.y = (c->H + 4 * rows - 1) / (4 * rows);
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
     if (c->pix_fmt == CRTFX_PIX_F16) {
-        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
-        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
-        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
     } else {
-        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
-        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
-        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg); }
+        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
     }
 }
 
-void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s) {
-    ProfEv pe(c, 1, g);
+// chain: the g frames are consecutive frames of ONE persistence recurrence (frame j + 1 blends with frame j's state); else independent frames.
+void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s, bool chain = false) {
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
     // plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend)
     bool lean = !identity && !c->force_generic && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);      // k_warp_lean reads the image through a 32-bit buffer resource
@@ -365,12 +365,24 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
                (o.blend == CRTFX_BLEND_NONE || o.blend == CRTFX_BLEND_RENDER);
     }
     if (lean) {
+        ProfEv pe(c, 1, g);
         const bool prom = (c->kp.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
         const bool rend = wg.o[0].blend == CRTFX_BLEND_RENDER;
-        if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, s, pe.e0, pe.e1); }
-        else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, s, pe.e0, pe.e1); }
+        if (rend) grid.z = 1;       // the g frames of a persistence chain: one after the other inside each thread, the state in registers
+        if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
+        else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
         return;
     }
+    if (chain && g > 1) {           // a persistence chain on the general kernel: its frames commit strictly in order (ref:1081-1105)
+        for (int j = 0; j < g; ++j) {
+            KWarpGroup one{};
+            one.pre[0] = wg.pre[j]; one.o[0] = wg.o[j];
+            ProfEv pj(c, 1, 1);
+            CRTFX_LAUNCH(k_warp, dim3(grid.x, grid.y, 1), dim3(256), 0, s, pj.e0, pj.e1, c->kp, one, identity ? 1 : 0);
+        }
+        return;
+    }
+    ProfEv pe(c, 1, g);
     CRTFX_LAUNCH(k_warp, grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, identity ? 1 : 0);
 }
 
@@ -853,11 +865,16 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         KWarpGroup wg{};
                         for (int j = 0; j < g; ++j) { wg.pre[j] = pre0 + (size_t)j * frame_elems; wg.o[j] = final_out(i + j); }
                         launch_warp_group(c, wg, g, !warp, sw);
-                    } else {                 // the persistence IIR commits frames strictly in order (ref:1081-1105)
-                        for (int j = 0; j < g; ++j) {
+                    } else {                 // the persistence IIR commits frames strictly in order (ref:1081-1105): runs of frames that
+                        int j = 0;           // blend with their predecessor go to one launch, each thread carrying its pixels' state
+                        while (j < g) {
+                            int nrun = 1;
+                            if (final_out(i + j).blend == CRTFX_BLEND_RENDER)
+                                while (j + nrun < g && final_out(i + j + nrun).blend == CRTFX_BLEND_RENDER) ++nrun;
                             KWarpGroup wg{};
-                            wg.pre[0] = pre0 + (size_t)j * frame_elems; wg.o[0] = final_out(i + j);
-                            launch_warp_group(c, wg, 1, !warp, sw);
+                            for (int k = 0; k < nrun; ++k) { wg.pre[k] = pre0 + (size_t)(j + k) * frame_elems; wg.o[k] = final_out(i + j + k); }
+                            launch_warp_group(c, wg, nrun, !warp, sw, nrun > 1);
+                            j += nrun;
                         }
                     }
                 }

@@ -2349,21 +2349,6 @@ __device__ __forceinline__ F3 buf_load_px(__amdgpu_buffer_rsrc_t rs, uint32_t of
     const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
     return F3{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2])};
 }
-__device__ __forceinline__ WarpTaps warp_load_buf(const KParams& P, __amdgpu_buffer_rsrc_t rs, int ix, int iy, int fx, int fy) {
-    WarpTaps t;
-    const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
-    const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
-    const float mx0 = (unsigned)ix < (unsigned)P.W ? wx0 : 0.0f, mx1 = (unsigned)(ix + 1) < (unsigned)P.W ? wx1 : 0.0f;
-    t.u00 = wy0 * mx0; t.u01 = wy0 * mx1; t.u10 = wy1 * mx0; t.u11 = wy1 * mx1;
-    // clamps keep the offset arithmetic inside 32 bits: iy to [-2, H] (both rows of the pair stay outside when iy is), ix to
-    // [-1, W] (the masks above come from the unclamped ix)
-    const int ixc = min(max(ix, -1), P.W), iyc = min(max(iy, -2), P.H);
-    const uint32_t off_a = (uint32_t)(iyc * P.W + ixc) * 12u;                    // a negative offset (rows -2, -1) wraps far past the buffer's end
-    const uint32_t off_b = off_a + (uint32_t)P.W * 12u;
-    t.A = buf_load_px(rs, off_a); t.B = buf_load_px(rs, off_a + 12u);
-    t.C = buf_load_px(rs, off_b); t.D = buf_load_px(rs, off_b + 12u);
-    return t;
-}
 template <typename T>
 __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T& o2) {
     o0 = (((T)t.A.x * (T)t.u00 + (T)t.B.x * (T)t.u01) + (T)t.C.x * (T)t.u10) + (T)t.D.x * (T)t.u11;
@@ -2371,50 +2356,88 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
     o2 = (((T)t.A.z * (T)t.u00 + (T)t.B.z * (T)t.u01) + (T)t.C.z * (T)t.u10) + (T)t.D.z * (T)t.u11;
 }
 
+// nseq (BLEND_RENDER only): the frames of G that each thread takes ONE AFTER THE OTHER — the persistence recurrence
+// ref:1092 is per pixel (state_n = clip(p * state_{n-1} + q * img_n) of the same pixel; the warp's gather reads the frame's
+// own pre-warp image, not the state), so a thread keeps its pixels' state in registers across the frames of a group: the
+// map coordinates and weights are computed once, and the float32 state (12 + 12 bytes per pixel and frame, more than
+// the frame's own 12 + 3) is read for the first frame and written behind the last one only (or behind every frame whose
+// record names a state buffer of its own: crtfx_process_batch's local_states).  Same operations in the same order per
+// pixel as one launch per frame: the same bits.  Other blends: nseq = 1, blockIdx.z = frame.
 template <bool PROMOTE, int BLEND, int PIX, int ROWS>
-__global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G) {
+__global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int nseq) {
     using T = typename std::conditional<PROMOTE, double, float>::type;
-    const float* __restrict__ pre = G.pre[blockIdx.z];
-    const KOut O = G.o[blockIdx.z];
+    const int z0 = BLEND == CRTFX_BLEND_RENDER ? 0 : (int)blockIdx.z;
+    const int nf = BLEND == CRTFX_BLEND_RENDER ? nseq : 1;
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
     const int ybase = blockIdx.y * (4 * ROWS) + (threadIdx.x >> 6);
     if (ybase >= P.H) return;
+    // (s_setprio 1 / 3 once the taps have been requested — a wave whose taps have arrived drains ahead of the waves still
+    // issuing loads — measured slower: 59.2 / 60.8 vs 56.6 us per 2-frame 4K launch.)
     const int x = min(x0 + lane, P.W - 1);
     const bool live = x0 + lane < P.W;
-    const float* state_in = O.state_in ? O.state_in : O.state;
-    const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 12u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, O.out_u8 ? (int)((uint32_t)P.H * (uint32_t)P.W * 3u) : 0, 0x00020000);
-    WarpTaps taps[ROWS];
-    F3 st[ROWS];
+    // geometry of this thread's ROWS pixels: frame-invariant
+    float u00[ROWS], u01[ROWS], u10[ROWS], u11[ROWS];
+    uint32_t off_a[ROWS], off_b[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int y = min(ybase + 4 * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
         int ix, iy, fx, fy;
         warp_coords(P, y, x, ix, iy, fx, fy);
-        taps[r] = warp_load_buf(P, pre_rs, ix, iy, fx, fy);
-        if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
+        const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
+        const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
+        const float mx0 = (unsigned)ix < (unsigned)P.W ? wx0 : 0.0f, mx1 = (unsigned)(ix + 1) < (unsigned)P.W ? wx1 : 0.0f;
+        u00[r] = wy0 * mx0; u01[r] = wy0 * mx1; u10[r] = wy1 * mx0; u11[r] = wy1 * mx1;
+        // clamps keep the offset arithmetic inside 32 bits: iy to [-2, H] (both rows of the pair stay outside when iy is), ix to
+        // [-1, W] (the masks above come from the unclamped ix)
+        const int ixc = min(max(ix, -1), P.W), iyc = min(max(iy, -2), P.H);
+        off_a[r] = (uint32_t)(iyc * P.W + ixc) * 12u;        // a negative offset (rows -2, -1) wraps far past the buffer's end
+        off_b[r] = off_a[r] + (uint32_t)P.W * 12u;
     }
-    // (s_setprio 1 / 3 from here on — a wave whose taps have arrived drains ahead of the waves still issuing loads — measured
-    // slower: 59.2 / 60.8 vs 56.6 us per 2-frame 4K launch.)
+    F3 st[ROWS];
+    if constexpr (BLEND == CRTFX_BLEND_RENDER) {
+        const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int y = ybase + 4 * r;
-        if (y >= P.H) break;                                  // wave-uniform
-        const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-        T v0, v1, v2;
-        warp_combine<T>(taps[r], v0, v1, v2);
-        if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
-            const T p = (T)O.p, q = (T)O.q;
-            v0 = clip01(p * (T)st[r].x + q * v0); v1 = clip01(p * (T)st[r].y + q * v1); v2 = clip01(p * (T)st[r].z + q * v2);
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = min(ybase + 4 * r, P.H - 1);
+            st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
         }
-        const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
-        if (O.state && live) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
-        if (O.out_u8) {
-            if constexpr (PIX == CRTFX_PIX_F16) {
-                store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
-            } else {
-                store_row_u8_buf(out_rs, ((uint32_t)y * (uint32_t)P.W + (uint32_t)x0) * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), (P.W & 3) == 0);
+    }
+    for (int jf = 0; jf < nf; ++jf) {
+        const float* __restrict__ pre = G.pre[z0 + jf];      // wave-uniform index: scalar loads
+        const KOut O = G.o[z0 + jf];
+        const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 12u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, O.out_u8 ? (int)((uint32_t)P.H * (uint32_t)P.W * 3u) : 0, 0x00020000);
+        // the state is stored behind this frame when nobody keeps it in registers for the next one: the group's last frame,
+        // or a frame whose record names its own state buffer
+        const bool keep_state = BLEND != CRTFX_BLEND_RENDER || jf == nf - 1 || G.o[z0 + jf + 1].state != O.state;
+        WarpTaps taps[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            taps[r].u00 = u00[r]; taps[r].u01 = u01[r]; taps[r].u10 = u10[r]; taps[r].u11 = u11[r];
+            taps[r].A = buf_load_px(pre_rs, off_a[r]); taps[r].B = buf_load_px(pre_rs, off_a[r] + 12u);
+            taps[r].C = buf_load_px(pre_rs, off_b[r]); taps[r].D = buf_load_px(pre_rs, off_b[r] + 12u);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int y = ybase + 4 * r;
+            if (y >= P.H) break;                                  // wave-uniform
+            const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+            T v0, v1, v2;
+            warp_combine<T>(taps[r], v0, v1, v2);
+            if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
+                const T p = (T)O.p, q = (T)O.q;
+                v0 = clip01(p * (T)st[r].x + q * v0); v1 = clip01(p * (T)st[r].y + q * v1); v2 = clip01(p * (T)st[r].z + q * v2);
+            }
+            const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
+            if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = F3{f0, f1, f2};
+            if (O.state && live && keep_state) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
+            if (O.out_u8) {
+                if constexpr (PIX == CRTFX_PIX_F16) {
+                    store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
+                } else {
+                    store_row_u8_buf(out_rs, ((uint32_t)y * (uint32_t)P.W + (uint32_t)x0) * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), (P.W & 3) == 0);
+                }
             }
         }
     }
