@@ -609,7 +609,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
             if ((rc = upload(c, c->dxo, p->fbd_xofs, (size_t)hw * 4)) || (rc = upload(c, c->dxw, p->fbd_xw, (size_t)hw * 4)) ||
                 (rc = upload(c, c->dyo, p->fbd_yofs, (size_t)hh * 4)) || (rc = upload(c, c->dyw, p->fbd_yw, (size_t)hh * 4))) return rc;
         }
-        const size_t need = (size_t)hw * hh * 3 * sizeof(float);
+        const size_t need = (size_t)MAX_GROUP * hw * hh * 3 * sizeof(float);      // one slot per frame of a grouped launch (k_half_group)
         if (c->ds.bytes < need) {
             free_buf(c->ds);
             HIP_TRY(c, hipMalloc(&c->ds.p, need));
@@ -884,6 +884,41 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 ++group_no;
                 continue;
             }
+        }
+        // ---- grouped path 2: persistence runs of the pointwise render chain (fast bloom, no warp: the reference CLI's defaults) --
+        // up to MAX_GROUP consecutive frames in two launches: their half-res bloom sources side by side (k_half_group), then
+        // k_point_lean_seq, each thread taking the frames one after the other with its pixels' state in registers
+        {
+            const uint32_t gates = fl & ~(uint32_t)CRTFX_F_WARP;
+            const bool seq_ok = !gauss && !c->split && blend_on && !warp && !c->force_generic && !c->force_runtime_flags &&
+                                (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
+            KGroup kg{};
+            const int gmax = n - i < MAX_GROUP ? n - i : MAX_GROUP;
+            for (; seq_ok && g < gmax; ++g) {
+                const crtfx_frame* f = frames ? &frames[i + g] : nullptr;
+                if ((fl & CRTFX_F_SCANLINES) && !(f && f->scan_row_dev)) break;
+                if (f && (f->glitch_offs_dev || f->overlay_rgba_dev || f->scan_plane_dev || f->noise_plane_dev)) break;
+                const KOut ko = final_out(i + g);
+                if (ko.blend != CRTFX_BLEND_RENDER) break;
+                kg.f[g] = make_kframe(frame_in(i + g), f);
+                kg.o[g] = ko;
+            }
+            if (g >= 2) {
+                c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
+                const bool pixelate = gates == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
+                dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
+                if (pixelate) { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                else { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
+                dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
+                ProfEv pe(c, 0, g);
+                if (pixelate) { if (f16) { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST_PIX, CRTFX_PIX_F16>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } else { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST_PIX, CRTFX_PIX_U8>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } }
+                else { if (f16) { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST, CRTFX_PIX_F16>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } else { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST, CRTFX_PIX_U8>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } }
+                HIP_TRY(c, hipGetLastError());
+                i += g;
+                continue;
+            }
+            g = 0;
         }
         // ---- general path, one frame ------------------------------------------------------------------------
         int rc = run_chain(c, frame_in(i), frames ? &frames[i] : nullptr, final_out(i), s);

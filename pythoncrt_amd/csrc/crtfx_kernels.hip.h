@@ -543,7 +543,7 @@ __device__ __forceinline__ void pk_fma_bcast(f32x2& acc, f32x2 w, bool whigh, un
 // SF / PIX: gate word and pixel format folded at compile time for a plain render frame (see k_point_lean), or
 // SF = 0xFFFFFFFF for the general build.
 template <uint32_t SF, int PIX>
-__global__ __launch_bounds__(256) void k_half(KParams Pin, KFrame Fin) {
+__device__ __forceinline__ void half_body(const KParams& Pin, const KFrame& Fin, float* __restrict__ ds) {
     KParams P = Pin;
     KFrame F = Fin;
     if constexpr (SF != 0xFFFFFFFFu) { P.flags = SF; P.pix = PIX; F.overlay_before = nullptr; }
@@ -573,8 +573,15 @@ __global__ __launch_bounds__(256) void k_half(KParams Pin, KFrame Fin) {
         for (int k = 0; k < 3; ++k)
             o[k] = (bloom_src(P, a[k]) * a0 + bloom_src(P, b[k]) * a1) * b0 + (bloom_src(P, c[k]) * a0 + bloom_src(P, d[k]) * a1) * b1;
     }
-    float* q = P.ds + ((size_t)j * P.hw + i) * 3;
+    float* q = ds + ((size_t)j * P.hw + i) * 3;
     q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+}
+template <uint32_t SF, int PIX>
+__global__ __launch_bounds__(256) void k_half(KParams Pin, KFrame Fin) { half_body<SF, PIX>(Pin, Fin, Pin.ds); }
+// the frames of a group, blockIdx.z = frame, each into its own slot of the scratch (slot stride = hh * hw * 3 floats)
+template <uint32_t SF, int PIX>
+__global__ __launch_bounds__(256) void k_half_group(KParams Pin, KGroup G) {
+    half_body<SF, PIX>(Pin, G.f[blockIdx.z], Pin.ds + (size_t)blockIdx.z * ((size_t)Pin.hh * Pin.hw * 3));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1130,6 +1137,94 @@ __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KO
                 const PackedPix pk = commit_pixel<T, true>(O, (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x, v[k][0], v[k][1], v[k][2]);
                 if (O.out_u8) store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
             }
+    }
+}
+
+// k_point_lean_seq — the persistence chain of the pointwise render chain (no warp behind it; the reference CLI's defaults:
+// fast bloom, persistence 0.2, ref:1171-1191): the nseq frames of G one after the other in each thread, its pixels' state in
+// registers (see k_warp_lean): the float32 state is read for the first frame and written behind the last only (or behind
+// every frame whose record names a state buffer of its own), and the upsample taps' indices and weights are computed
+// once.  Frame jf's half-res bloom source sits in slot jf of the scratch (k_half_group).  Same operations per pixel in
+// the same order as k_point_lean<SF, PIX, CRTFX_BLEND_RENDER> frame by frame: the same bits.
+template <uint32_t SF, int PIX>
+__global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, int nseq) {
+    __shared__ float lut[2 * LUT_STRIDE];
+    constexpr int ROWS = CRTFX_POINT_ROWS;
+    KParams P = Pin;
+    P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    if constexpr ((SF & CRTFX_F_TRIAD) && (SF & CRTFX_F_TRIAD_LUT)) {
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int waves = blockDim.x >> 6;
+    const int ybase = blockIdx.y * (waves * ROWS) + (threadIdx.x >> 6);
+    if (ybase >= P.H) return;
+    const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
+    using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
+    int yr[ROWS];
+    uint32_t o00[ROWS], o01[ROWS], o10[ROWS], o11[ROWS];      // float offsets of the four half-res taps inside a slot
+    float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
+    F3 st[ROWS];
+    const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int y = yr[k] = min(ybase + k * waves, P.H - 1);     // a row past the bottom redoes the last one; its stores are skipped
+        if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
+            const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
+            const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
+            a1[k] = P.ux_a[x]; a0[k] = 1.0f - a1[k]; b1[k] = P.uy_a[y]; b0[k] = 1.0f - b1[k];
+            o00[k] = (uint32_t)(sy * P.hw + sx) * 3u; o01[k] = (uint32_t)(sy * P.hw + sx1) * 3u;
+            o10[k] = (uint32_t)(sy1 * P.hw + sx) * 3u; o11[k] = (uint32_t)(sy1 * P.hw + sx1) * 3u;
+        }
+        st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
+    }
+    const size_t slot = (size_t)P.hh * P.hw * 3;
+    for (int jf = 0; jf < nseq; ++jf) {
+        KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
+        F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+        KOut O = G.o[jf];
+        O.pix = PIX;
+        const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
+        const float* __restrict__ ds = P.ds + (size_t)jf * slot;
+        T v[ROWS][3];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const int y = yr[k];
+            const PixMasks M = load_masks(P, F, y, x);
+            float r, g, b;
+            fetch_graded(P, F, y, x, r, g, b);
+            if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
+                const F3 p00 = *reinterpret_cast<const F3*>(ds + o00[k]);
+                const F3 p01 = *reinterpret_cast<const F3*>(ds + o01[k]);
+                const F3 p10 = *reinterpret_cast<const F3*>(ds + o10[k]);
+                const F3 p11 = *reinterpret_cast<const F3*>(ds + o11[k]);
+                const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
+                const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
+                const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
+                r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+            }
+            tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
+        }
+        const T p = (T)O.p, q = (T)O.q;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            if (ybase + k * waves < P.H) {           // wave-uniform
+                const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
+                const float f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
+                const float f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
+                const float f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
+                st[k] = F3{f0, f1, f2};
+                if (O.state && keep_state) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
+                if (O.out_u8) {
+                    PackedPix pk;
+                    if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+                    else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+                    store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+                }
+            }
+        }
     }
 }
 #endif  // CRTFX_MAIN_TU
