@@ -1167,10 +1167,16 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
     uint32_t o00[ROWS], o01[ROWS], o10[ROWS], o11[ROWS];      // float offsets of the four half-res taps inside a slot
     float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
     F3 st[ROWS];
+    PixMasks M0[ROWS];                           // triad mask and vignette gain of the pixel: frame-invariant (the scanline gain is not)
     const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
         const int y = yr[k] = min(ybase + k * waves, P.H - 1);     // a row past the bottom redoes the last one; its stores are skipped
+        {
+            KFrame F0 = G.f[0];
+            F0.scan_plane = nullptr;
+            M0[k] = load_masks(P, F0, y, x);
+        }
         if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
             const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
             const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
@@ -1192,7 +1198,8 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             const int y = yr[k];
-            const PixMasks M = load_masks(P, F, y, x);
+            PixMasks M = M0[k];
+            if constexpr ((SF & CRTFX_F_SCANLINES) != 0) M.sl = F.scan_row[y];
             float r, g, b;
             fetch_graded(P, F, y, x, r, g, b);
             if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
