@@ -358,7 +358,8 @@ void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, h
 void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s, bool chain = false) {
     dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
     // plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend)
-    bool lean = !identity && !c->force_generic && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);      // k_warp_lean reads the image through a 32-bit buffer resource
+    bool lean = !c->force_generic && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);      // k_warp_lean reads the image through a 32-bit buffer resource
+    if (identity && !(wg.o[0].blend == CRTFX_BLEND_RENDER && c->pix_fmt == CRTFX_PIX_U8)) lean = false;      // commit-only lean build: render blend, uint8 frames
     for (int j = 0; j < g && lean; ++j) {
         const KOut& o = wg.o[j];
         lean = !o.overlay_after && !o.glitch_offs && !o.out_f32 && o.blend == wg.o[0].blend &&
@@ -369,6 +370,12 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
         const bool prom = (c->kp.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
         const bool rend = wg.o[0].blend == CRTFX_BLEND_RENDER;
         if (rend) grid.z = 1;       // the g frames of a persistence chain: one after the other inside each thread, the state in registers
+        if (identity) {             // no warp behind the Gaussian chain: the blend and the commit only
+            grid.y = (c->H + 7) / 8;
+            if (prom) { CRTFX_LAUNCH((k_warp_lean<true, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g); }
+            else { CRTFX_LAUNCH((k_warp_lean<false, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g); }
+            return;
+        }
         if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
         else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
         return;

@@ -2465,7 +2465,8 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 // the frame's own 12 + 3) is read for the first frame and written behind the last one only (or behind every frame whose
 // record names a state buffer of its own: crtfx_process_batch's local_states).  Same operations in the same order per
 // pixel as one launch per frame: the same bits.  Other blends: nseq = 1, blockIdx.z = frame.
-template <bool PROMOTE, int BLEND, int PIX, int ROWS>
+// IDENT: no warp — the commit alone (a persistence blend behind the Gaussian chain with warp off): the tap is the pixel itself.
+template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false>
 __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int nseq) {
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const int z0 = BLEND == CRTFX_BLEND_RENDER ? 0 : (int)blockIdx.z;
@@ -2484,6 +2485,11 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int y = min(ybase + 4 * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
+        if constexpr (IDENT) {
+            u00[r] = 1.0f; u01[r] = u10[r] = u11[r] = 0.0f;
+            off_a[r] = off_b[r] = ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 12u;
+            continue;
+        }
         int ix, iy, fx, fy;
         warp_coords(P, y, x, ix, iy, fx, fy);
         const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
@@ -2517,8 +2523,11 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             taps[r].u00 = u00[r]; taps[r].u01 = u01[r]; taps[r].u10 = u10[r]; taps[r].u11 = u11[r];
-            taps[r].A = buf_load_px(pre_rs, off_a[r]); taps[r].B = buf_load_px(pre_rs, off_a[r] + 12u);
-            taps[r].C = buf_load_px(pre_rs, off_b[r]); taps[r].D = buf_load_px(pre_rs, off_b[r] + 12u);
+            taps[r].A = buf_load_px(pre_rs, off_a[r]);
+            if constexpr (!IDENT) {
+                taps[r].B = buf_load_px(pre_rs, off_a[r] + 12u);
+                taps[r].C = buf_load_px(pre_rs, off_b[r]); taps[r].D = buf_load_px(pre_rs, off_b[r] + 12u);
+            }
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -2526,7 +2535,8 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
             if (y >= P.H) break;                                  // wave-uniform
             const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
             T v0, v1, v2;
-            warp_combine<T>(taps[r], v0, v1, v2);
+            if constexpr (IDENT) { v0 = (T)taps[r].A.x; v1 = (T)taps[r].A.y; v2 = (T)taps[r].A.z; }
+            else warp_combine<T>(taps[r], v0, v1, v2);
             if constexpr (BLEND == CRTFX_BLEND_RENDER) {           // ref:1092
                 const T p = (T)O.p, q = (T)O.q;
                 v0 = clip01(p * (T)st[r].x + q * v0); v1 = clip01(p * (T)st[r].y + q * v1); v2 = clip01(p * (T)st[r].z + q * v2);

@@ -440,7 +440,8 @@ def test_kernel_variants_agree(pc, monkeypatch):
         for rs in (RenderSettings(), RenderSettings(pixel_size=1, persistence=0.0), RenderSettings(warp_strength=0.2),
                    baseline_config(2)[0], baseline_config(4)[0],
                    RenderSettings(fast_bloom=False, bloom_sigma=2.0, scanline_angle=12.0, scanline_thickness=2.0, grain_size=2, warp_strength=0.15),
-                   RenderSettings(fast_bloom=False, bloom_sigma=5.0, grain_size=3, pixel_size=1, persistence=0.0)):
+                   RenderSettings(fast_bloom=False, bloom_sigma=5.0, grain_size=3, pixel_size=1, persistence=0.0),
+                   RenderSettings(fast_bloom=False, bloom_sigma=2.0), RenderSettings(fast_bloom=False, bloom_sigma=3.0, pixel_size=1)):      # Gaussian + persistence, no warp
             pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
             keep = torch.empty((4, h, w, 3), dtype=torch.float32, device=dev) if rs.persistence > 0 else None
             o, st = pipe.run(clip4, first_index=2, local_states=keep)
@@ -849,13 +850,14 @@ def test_4k_render_loop_against_oracle(pc):
     assert d.max() <= 1 and (d != 0).mean() < 1e-3, (int(d.max()), float((d != 0).mean()))
 
 
-@pytest.mark.parametrize("sigma", [11.0, 45.0])          # radii 33, 135
-def test_render_loop_any_sigma(pc, sigma):
+@pytest.mark.parametrize("sigma,warp", [(11.0, 0.15), (45.0, 0.15), (3.0, 0.0), (1.2, 0.0), (11.0, 0.0)])          # radii 33, 135 | 9, 4, 33 with the commit-only k_warp_lean
+def test_render_loop_any_sigma(pc, sigma, warp):
     """The render loop (crtfx_process_batch: warp, persistence 0.5, in-kernel grain) with a bloom sigma beyond the GUI's
-    range — the split path behind the same entry point — against the oracle's in-order render (ref:609-610 takes any sigma)."""
+    range — the split path behind the same entry point — against the oracle's in-order render (ref:609-610 takes any sigma);
+    and with the warp off: the persistence chain behind the Gaussian kernels then runs in the commit-only build of k_warp_lean."""
     import dataclasses
     from pythoncrt_amd.pipeline import FramePipeline, baseline_config
-    rs = dataclasses.replace(baseline_config(4)[0], bloom_sigma=sigma)
+    rs = dataclasses.replace(baseline_config(4)[0], bloom_sigma=sigma, warp_strength=warp)
     h, w = 120, 200
     dev = torch.device("cuda", torch.cuda.current_device())
     n, first, seed = 3, 5, 99
