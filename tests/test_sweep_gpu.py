@@ -18,7 +18,7 @@ def draw_settings(rng):
     return RenderSettings(
         scanline_strength=pick(0.0, 0.6, 1.0), triad_strength=pick(0.0, 0.35, 0.9), triad_gamma=pick(2.2, 1.0, 0.7),
         triad_preserve_luma=bool(rng.integers(2)), triad_softness=pick(0.0, 0.5, 1.4), aberration_px=int(pick(-8, -1, 0, 1, 3)),
-        bloom_sigma=pick(0.0, 0.5, 1.2, 3.0, 4.4), bloom_strength=pick(0.0, 0.25, 0.8), bloom_threshold=pick(0.0, 0.0, 0.3),
+        bloom_sigma=pick(0.0, 0.5, 1.2, 3.0, 4.4, 11.0, 25.0), bloom_strength=pick(0.0, 0.25, 0.8), bloom_threshold=pick(0.0, 0.0, 0.3),
         noise_strength=pick(0.0, 1.5, 6.0), vignette_strength=pick(0.0, 0.25, 1.0), persistence=pick(0.0, 0.2, 0.9),
         scanline_speed_px_s=pick(30.0, 0.0, -12.5), scanline_period_px=pick(2.0, 3.7), fast_bloom=fast, pixel_size=int(pick(1, 1, 2, 3)),
         brightness=pick(0.0, 0.0, 0.08), contrast=pick(1.0, 1.0, 1.25), gamma=1.0, saturation=pick(1.0, 1.0, 1.4), temperature=pick(0.0, 0.0, -0.5),
@@ -38,7 +38,7 @@ def test_random_render_matches_oracle(case):
     rng = np.random.default_rng(1000 + case)
     h, w = SIZES[case % len(SIZES)]
     rs = draw_settings(rng)
-    n, first, fps, seed = 4, int(rng.integers(0, 50)), 25.0, int(rng.integers(1 << 40))
+    n, first, fps, seed = 6, int(rng.integers(0, 50)), 25.0, int(rng.integers(1 << 40))      # 6 frames: a full 4-frame persistence run behind frame 0, then a partial one
     frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     dev = torch.device("cuda", torch.cuda.current_device())
     pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed)
