@@ -892,35 +892,70 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 continue;
             }
         }
-        // ---- grouped path 2: persistence runs of the pointwise render chain (fast bloom, no warp: the reference CLI's defaults) --
-        // up to MAX_GROUP consecutive frames in two launches: their half-res bloom sources side by side (k_half_group), then
-        // k_point_lean_seq, each thread taking the frames one after the other with its pixels' state in registers
+        // ---- grouped path 2: runs of frames of the pointwise render chain (fast / no bloom, no warp: the reference CLI's defaults
+        // and everything one knob away from them) — up to MAX_GROUP consecutive frames that all blend with their predecessor
+        // (persistence) or that do not blend at all, in two launches: their half-res bloom sources side by side (k_half_group),
+        // then k_point_lean_seq / k_point_sel_seq, each thread taking the frames one after the other with its pixels' state in registers
         {
             const uint32_t gates = fl & ~(uint32_t)CRTFX_F_WARP;
-            const bool seq_ok = !gauss && !c->split && blend_on && !warp && !c->force_generic && !c->force_runtime_flags &&
-                                (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
+            const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
+            const bool seq_ok = !gauss && !c->split && !c->force_generic && !((fl & CRTFX_F_NOISE) && c->kp.grain > 1) &&
+                                (!warp || (size_t)c->H * c->W * 12 < ((size_t)1 << 31));      // with a warp behind it: pre-warp images parked, then k_warp_lean
+            const bool lean_gates = !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full;
+            bool lean = lean_gates;
             KGroup kg{};
-            const int gmax = n - i < MAX_GROUP ? n - i : MAX_GROUP;
+            KWarpGroup wg{};                     // warp on: the frames' FINAL outputs (the point kernels then only park pre-warp images)
+            int gmax = n - i < MAX_GROUP ? n - i : MAX_GROUP;
+            if (warp && gmax > c->pre_frames) gmax = c->pre_frames;
             for (; seq_ok && g < gmax; ++g) {
                 const crtfx_frame* f = frames ? &frames[i + g] : nullptr;
-                if ((fl & CRTFX_F_SCANLINES) && !(f && f->scan_row_dev)) break;
-                if (f && (f->glitch_offs_dev || f->overlay_rgba_dev || f->scan_plane_dev || f->noise_plane_dev)) break;
+                if ((fl & CRTFX_F_SCANLINES) && !(f && (f->scan_row_dev || f->scan_plane_dev))) break;
+                if (f && f->glitch_offs_dev) break;
                 const KOut ko = final_out(i + g);
-                if (ko.blend != CRTFX_BLEND_RENDER) break;
+                if (ko.blend != CRTFX_BLEND_RENDER && ko.blend != CRTFX_BLEND_NONE) break;
+                if (g > 0 && ko.blend != (warp ? wg.o[0].blend : kg.o[0].blend)) break;       // a run = frames that all blend with their predecessor, or frames that do not blend at all
                 kg.f[g] = make_kframe(frame_in(i + g), f);
-                kg.o[g] = ko;
+                if (warp) {
+                    wg.pre[g] = c->pre + (size_t)g * frame_elems; wg.o[g] = ko;
+                    KOut k1{};
+                    k1.pre = c->pre + (size_t)g * frame_elems; k1.pix = c->pix_fmt; k1.dbg = c->dbg;
+                    kg.o[g] = k1;
+                } else kg.o[g] = ko;
+                if (kg.f[g].scan_plane || kg.f[g].noise_plane || kg.f[g].overlay_before || kg.o[g].overlay_after) lean = false;
             }
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = gates == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
-                if (pixelate) { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
-                else { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                if (fastb) {
+                    dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
+                    if (!lean) hipLaunchKernelGGL((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, c->kp, kg);
+                    else if (pixelate) { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                    else { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                }
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
-                dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
                 ProfEv pe(c, 0, g);
-                if (pixelate) { if (f16) { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST_PIX, CRTFX_PIX_F16>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } else { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST_PIX, CRTFX_PIX_U8>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } }
-                else { if (f16) { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST, CRTFX_PIX_F16>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } else { CRTFX_LAUNCH((k_point_lean_seq<SF_FAST, CRTFX_PIX_U8>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } }
+                if (lean) {
+                    dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
+#define CRTFX_SEQ(SFV, PIXV)                                                                                                                             \
+                    do {                                                                                                                                     \
+                        if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_lean_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } \
+                        else { CRTFX_LAUNCH((k_point_lean_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }                      \
+                    } while (0)
+                    if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
+                    else { if (f16) CRTFX_SEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST, CRTFX_PIX_U8); }
+#undef CRTFX_SEQ
+                } else {
+                    dim3 gp((c->W + TW - 1) / TW, (c->H + waves - 1) / waves);
+                    const bool one = !(fl & CRTFX_F_PIXELATE) && !fastb;
+                    if (f16) {
+                        if (one) { CRTFX_LAUNCH((k_point_sel_seq<CRTFX_PIX_F16, true>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }
+                        else { CRTFX_LAUNCH((k_point_sel_seq<CRTFX_PIX_F16, false>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }
+                    } else {
+                        if (one) { CRTFX_LAUNCH((k_point_sel_seq<CRTFX_PIX_U8, true>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }
+                        else { CRTFX_LAUNCH((k_point_sel_seq<CRTFX_PIX_U8, false>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }
+                    }
+                }
+                if (warp) launch_warp_group(c, wg, g, false, s, wg.o[0].blend == CRTFX_BLEND_RENDER && g > 1);
                 HIP_TRY(c, hipGetLastError());
                 i += g;
                 continue;

@@ -952,14 +952,14 @@ __global__ __launch_bounds__(1024) void k_point(KParams Pin, KFrame F, KOut O) {
 // issued unconditionally in two groups (tables and planes; then the samples and half-res taps that need the index
 // tables) and the stage arithmetic is gated afterwards (branches without loads cost nothing).  Same arithmetic, same bits as k_point (test_kernel_variants_agree); grain_size > 1 stays on k_point.
 template <typename T>
-__device__ __forceinline__ void point_finish(const KParams& P, const KFrame& F, const KOut& O, int y, int x, uint32_t pix, bool row_live,
+__device__ __forceinline__ F3 point_finish(const KParams& P, const KFrame& F, const KOut& O, int y, int x, uint32_t pix, bool row_live,
                                              const PixMasks& M, float r, float g, float b, const float* lut, uint32_t ov_after, F3 st,
                                              int x0, int lane) {
     T v0, v1, v2;
     tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v0, v1, v2);
     if (O.pre) {                                 // two-kernel path: park the pre-warp pixel for k_warp
         if (row_live) *reinterpret_cast<F3*>(O.pre + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
-        return;
+        return F3{(float)v0, (float)v1, (float)v2};
     }
     if (O.overlay_after) overlay_blend_px<T>(ov_after, v0, v1, v2);      // the pixel was loaded above; no load inside this branch
     if (O.out_f32 && row_live) *reinterpret_cast<F3*>(O.out_f32 + pix * 3u) = F3{(float)v0, (float)v1, (float)v2};
@@ -978,6 +978,7 @@ __device__ __forceinline__ void point_finish(const KParams& P, const KFrame& F, 
         else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
         store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), pk);
     }
+    return F3{f0, f1, f2};
 }
 
 // ONE: neither pixelate nor fast bloom is on (the host checks), so no sample address waits for an index-table load and
@@ -1060,6 +1061,99 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     PixMasks M{tm.x, tm.y, tm.z, sl, vfull ? vfv : vignette_gain(P, nx2, ny2), zn, F.noise_plane != nullptr};
     if (promotes(P)) point_finish<double>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
     else point_finish<float>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
+}
+
+// k_point_sel_seq — k_point_sel for a RUN of frames (crtfx_process_batch): frames that all blend with their predecessor
+// (persistence: the state travels in registers, see k_warp_lean) or that do not blend at all, one after the other in each
+// thread; the triad LUTs are staged once, the frame-invariant loads (index maps, mask, vignette, overlays) issue once.
+// Frame jf's half-res bloom source sits in slot jf of the scratch (k_half_group).  Same arithmetic per frame as k_point_sel.
+template <int PIX, bool ONE>
+__global__ __launch_bounds__(1024) void k_point_sel_seq(KParams Pin, KGroup G, int nseq) {
+    __shared__ float lut[2 * LUT_STRIDE];
+    KParams P = Pin;
+    P.pix = PIX; P.grain = 1;
+    const uint32_t fl = P.flags;
+    const float* ones = P.consts;
+    const float* zf = P.consts + 4;
+    const int* zi = reinterpret_cast<const int*>(zf);
+    const double* zd = reinterpret_cast<const double*>(zf);
+    const uint32_t* zu = reinterpret_cast<const uint32_t*>(zf);
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int yraw = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool row_live = yraw < P.H;              // wave-uniform; rows past the bottom redo the last row without storing
+    const int y = min(yraw, P.H - 1);
+    const int x = min(x0 + lane, P.W - 1);         // lanes past the right edge redo the last pixel: same values, same stores
+    const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+    if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT))
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    // ---- frame-invariant loads -------------------------------------------------------------------------------------
+    const bool pxl = !ONE && (fl & CRTFX_F_PIXELATE) != 0;
+    const bool fb = !ONE && (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
+    int xm = 0, ym = 0, ux = 0, uy = 0;
+    float ua = 0.0f, ub = 0.0f;
+    if constexpr (!ONE) {
+        xm = *(pxl ? P.xmap + x : zi); ym = *(pxl ? P.ymap + y : zi);
+        ux = *(fb ? P.ux_ofs + x : zi); uy = *(fb ? P.uy_ofs + y : zi);
+        ua = *(fb ? P.ux_a + x : zf); ub = *(fb ? P.uy_a + y : zf);
+    }
+    const bool tri = (fl & CRTFX_F_TRIAD) != 0;
+    const F3 tm = *reinterpret_cast<const F3*>(tri ? (P.triad_full ? P.triad_full + (size_t)pix * 3 : P.triad_row + x * 3) : ones);
+    const bool vg = (fl & CRTFX_F_VIGNETTE) != 0, vfull = vg && P.vig_full != nullptr;
+    const double vfv = *(vfull ? P.vig_full + pix : zd);
+    const double nx2 = *((vg && !vfull) ? P.vig_nx2 + x : zd), ny2 = *((vg && !vfull) ? P.vig_ny2 + y : zd);
+    const KOut O0 = G.o[0];
+    const float* sin0 = O0.state_in ? O0.state_in : O0.state;
+    F3 st = *reinterpret_cast<const F3*>((O0.blend != CRTFX_BLEND_NONE) ? sin0 + (size_t)pix * 3 : zf);
+    const int xs = pxl ? xm : x, ys = pxl ? ym : y;
+    int xr = xs, xb = xs;
+    if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }      // ref:573-575
+    const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
+    const int hw = fb ? P.hw : 1, hh = fb ? P.hh : 1;
+    const int ux1 = min(ux + 1, hw - 1), uy1 = min(uy + 1, hh - 1);
+    const double vgain = vfull ? vfv : vignette_gain(P, nx2, ny2);
+    const size_t slot = (size_t)P.hh * P.hw * 3;
+    __syncthreads();                               // LUTs visible
+    for (int jf = 0; jf < nseq; ++jf) {
+        const KFrame F = G.f[jf];                  // wave-uniform index: scalar loads
+        KOut O = G.o[jf];
+        O.pix = PIX;
+        const bool chain = O.blend == CRTFX_BLEND_RENDER;
+        const bool keep_state = !chain || jf == nseq - 1 || G.o[jf + 1].state != O.state;
+        // ---- this frame's loads: one group -------------------------------------------------------------------------
+        const float sl = *((fl & CRTFX_F_SCANLINES) ? (F.scan_plane ? F.scan_plane + pix : F.scan_row + y) : ones);
+        const uint32_t ov_before = *(F.overlay_before ? reinterpret_cast<const uint32_t*>(F.overlay_before) + pix : zu);
+        const uint32_t ov_after = *(O.overlay_after ? reinterpret_cast<const uint32_t*>(O.overlay_after) + pix : zu);
+        const float zn = *(F.noise_plane ? F.noise_plane + pix : zf);
+        const RawRGB raw = load_raw(PIX, F.in, row + (uint32_t)xr * 3u, row + (uint32_t)xs * 3u + 1u, row + (uint32_t)xb * 3u + 2u);
+        F3 p00{0, 0, 0}, p01{0, 0, 0}, p10{0, 0, 0}, p11{0, 0, 0};
+        if constexpr (!ONE) {
+            const float* dsb = fb ? P.ds + (size_t)jf * slot : zf;
+            p00 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux) * 3);
+            p01 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy * hw + ux1) * 3);
+            p10 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux) * 3);
+            p11 = *reinterpret_cast<const F3*>(dsb + ((size_t)uy1 * hw + ux1) * 3);
+        }
+        // ---- arithmetic, gated ---------------------------------------------------------------------------------------
+        float r, g, b;
+        if (P.grade_lut && (fl & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+        else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+        if (F.overlay_before) overlay_blend_px<float>(ov_before, r, g, b);
+        if (fb) {
+            const float a1 = ua, a0 = 1.0f - a1, b1 = ub, b0 = 1.0f - b1;
+            const float bl0 = (p00.x * a0 + p01.x * a1) * b0 + (p10.x * a0 + p11.x * a1) * b1;
+            const float bl1 = (p00.y * a0 + p01.y * a1) * b0 + (p10.y * a0 + p11.y * a1) * b1;
+            const float bl2 = (p00.z * a0 + p01.z * a1) * b0 + (p10.z * a0 + p11.z * a1) * b1;
+            r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+        }
+        PixMasks M{tm.x, tm.y, tm.z, sl, vgain, zn, F.noise_plane != nullptr};
+        KOut Ow = O;
+        if (!keep_state) Ow.state = nullptr;       // the next frame of the run takes the state from this thread's registers
+        F3 fin;
+        if (promotes(P)) fin = point_finish<double>(P, F, Ow, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
+        else fin = point_finish<float>(P, F, Ow, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
+        if (chain) st = fin;
+    }
 }
 
 // k_point_lean — k_point for a plain render frame: gate word, pixel format and blend mode are compile-time, no
@@ -1146,7 +1240,8 @@ __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KO
 // every frame whose record names a state buffer of its own), and the upsample taps' indices and weights are computed
 // once.  Frame jf's half-res bloom source sits in slot jf of the scratch (k_half_group).  Same operations per pixel in
 // the same order as k_point_lean<SF, PIX, CRTFX_BLEND_RENDER> frame by frame: the same bits.
-template <uint32_t SF, int PIX>
+// BLENDM = CRTFX_BLEND_NONE: the same grouping for independent frames (persistence 0): no state, the rest as above.
+template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, int nseq) {
     __shared__ float lut[2 * LUT_STRIDE];
     constexpr int ROWS = CRTFX_POINT_ROWS;
@@ -1184,7 +1279,7 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
             o00[k] = (uint32_t)(sy * P.hw + sx) * 3u; o01[k] = (uint32_t)(sy * P.hw + sx1) * 3u;
             o10[k] = (uint32_t)(sy1 * P.hw + sx) * 3u; o11[k] = (uint32_t)(sy1 * P.hw + sx1) * 3u;
         }
-        st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
+        if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
     const size_t slot = (size_t)P.hh * P.hw * 3;
     for (int jf = 0; jf < nseq; ++jf) {
@@ -1215,15 +1310,25 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
             tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
         }
         const T p = (T)O.p, q = (T)O.q;
+        if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                if (ybase + k * waves < P.H)
+                    *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {
             if (ybase + k * waves < P.H) {           // wave-uniform
                 const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
-                const float f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
-                const float f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
-                const float f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
-                st[k] = F3{f0, f1, f2};
-                if (O.state && keep_state) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
+                float f0, f1, f2;
+                if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
+                    f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
+                    f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
+                    f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
+                    st[k] = F3{f0, f1, f2};
+                } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
+                if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
                 if (O.out_u8) {
                     PackedPix pk;
                     if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
