@@ -188,7 +188,9 @@ int crtfx_halo_correct_batch(crtfx_ctx* ctx, const float* local_base_dev, const 
  * run (blend RENDER; the first frame passes through when first_has_state == 0).
  * local_states_base (optional) receives every frame's float state at stride H*W*3 floats (frame i blends against
  * state i-1 there and writes state i: no copy per frame; it must not overlap state_inout_dev, which receives the
- * last state at the end). */
+ * last state at the end).  Consecutive frames may be executed as one grouped launch (several frames per grid; a run of frames
+ * that blend with their predecessor keeps its state in registers): state_inout_dev is defined when the call's work has
+ * completed on `stream`, not frame by frame. */
 int crtfx_process_batch(crtfx_ctx* ctx, const void* frames_base, size_t frame_stride_bytes,
                         void* out_base, size_t out_stride_bytes, int n, const crtfx_frame* frames,
                         float* state_inout_dev, double persistence, int first_has_state,

@@ -448,6 +448,8 @@ def test_kernel_variants_agree(pc, monkeypatch):
             res.append(o.cpu().numpy())
             if st is not None:
                 res.append(st.cpu().numpy())
+            if keep is not None:
+                res.append(keep.cpu().numpy())      # the per-frame states the sharded render's fix-up reads (written even when a run keeps its state in registers)
         outs[name] = res
     effects._tls.engines = {}
     for name in ("cc", "no_cc", "runtime_flags", "generic", "split", "split_plane"):
