@@ -256,18 +256,42 @@ class FramePipeline:
 # state, correction = crtfx_halo_correct_quantise per frame.
 # ---------------------------------------------------------------------------------------
 
+class _LocalStates:
+    """What ShardedRender reads of a chunk's local states: the first k of them (the frames the fix-up re-quantises) and the
+    chunk-final one (the frame that travels to the next rank) — indexable like the (n, H, W, 3) tensor they stand for."""
+
+    def __init__(self, first: torch.Tensor, final: torch.Tensor, n: int):
+        self.first, self.final, self.n = first, final, int(n)
+        self.shape = (self.n,) + tuple(final.shape)
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            stop = self.n if key.stop is None else key.stop
+            if (key.start or 0) != 0 or key.step not in (None, 1) or stop > self.first.shape[0]:
+                raise IndexError(f"local states kept for frames [0, {self.first.shape[0]}) and frame {self.n - 1} only (asked: {key})")
+            return self.first[:stop]
+        k = int(key)
+        if k in (self.n - 1, -1):
+            return self.final
+        return self.first[k]
+
+
 class GpuShardEngine:
     """Buffers of one rank's chunks.  `slots` = 2 double-buffers the per-frame local states and the output frames so that
     round r+1's scan can be enqueued while round r's state frame is still travelling (ShardedRender overlap=True).
-    The float32 local states (chunk x H x W x 3 per slot — 288 GB of HBM is what lets a chunk cover the IIR's whole
-    settling time) are only allocated when the render has persistence."""
+    Per-frame float32 local states are kept for the frames the fix-up can change only — the first settle_frames(p, 2^-26)
+    of a chunk (26 at p = 0.5, the whole chunk when it is shorter than that: the exact-chain schedule) — plus the
+    chunk-final state; the rest of the chunk runs with its state in registers (crtfx_process_batch's runs)."""
 
     def __init__(self, pipe: FramePipeline, chunk: int, slots: int = 1):
+        from .shard import settle_frames
         self.pipe = pipe
         self.slots = int(slots)
         h, w = pipe.h, pipe.w
         p = pipe.rs.persistence
-        self.local = [torch.empty((chunk, h, w, 3), dtype=torch.float32, device=pipe.device) for _ in range(self.slots)] if p > 0.0 else None
+        self.keep = min(int(chunk), settle_frames(p, 2.0 ** -26)) if p > 0.0 else 0
+        self.local = [torch.empty((self.keep, h, w, 3), dtype=torch.float32, device=pipe.device) for _ in range(self.slots)] if p > 0.0 else None
+        self.final = [torch.empty((h, w, 3), dtype=torch.float32, device=pipe.device) for _ in range(self.slots)] if p > 0.0 else None
         self.out_slots = [torch.empty((chunk, h, w, 3), dtype=pipe.dtype, device=pipe.device) for _ in range(self.slots)]
         self.out = self.out_slots[0]
         self.zero = torch.zeros((h, w, 3), dtype=torch.float32, device=pipe.device) if p > 0.0 else None
@@ -282,12 +306,20 @@ class GpuShardEngine:
             self.pipe.run(frames, first_index=first_index, out=out[:n], records=recs)
             return None, out[:n]
         local = self.local[slot % self.slots]
+        final = self.final[slot % self.slots]
         state = None
         if not clip_start:                                      # zero incoming state, blend from the first frame on
             state = self.state
             state.copy_(self.zero)
-        self.pipe.run(frames, first_index=first_index, state=state, out=out[:n], records=recs, local_states=local[:n])
-        return local[:n], out[:n]
+        if recs is None:
+            recs = self.pipe.frame_records(first_index, n)
+        arr, hold = recs
+        k = min(n, self.keep)
+        _, st = self.pipe.run(frames[:k], first_index=first_index, state=state, out=out[:k], records=(arr[:k], hold), local_states=local[:k])
+        if n > k:                                               # the rest of the chunk continues from state k - 1 (left in st), no per-frame states
+            _, st = self.pipe.run(frames[k:], first_index=first_index + k, state=st, out=out[k:n], records=(arr[k:], hold))
+        final.copy_(st)                                         # its own buffer per slot: the next round's scan reuses self.state while this one travels
+        return _LocalStates(local[:k], final, n), out[:n]
 
     def sequential_scan(self, frames, first_index, state):
         """world 1: the chunk continues from the true state of the previous one (None at the start of the clip)."""

@@ -476,16 +476,39 @@ def test_sharded_persistence_pieces_on_gpu():
     eng = GpuShardEngine(pipe, B)
     local, out = eng.local_scan(frames[B:], first_index=B, clip_start=False)
     carry = states[B - 1].clone()
-    eng.correct(local, carry, rs.persistence, out)
+    eng.correct(local[:B], carry, rs.persistence, out)
     torch.cuda.synchronize()
     d = (out.cpu().to(torch.int16) - seq_out[B:].cpu().to(torch.int16)).abs()
     assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3
-    true_states = local + torch.tensor([rs.persistence ** (j + 1) for j in range(B)], device=dev).view(B, 1, 1, 1) * carry
+    true_states = local[:B] + torch.tensor([rs.persistence ** (j + 1) for j in range(B)], device=dev).view(B, 1, 1, 1) * carry
     assert float((true_states - states[B:]).abs().max()) < 5e-7
+    assert torch.equal(local[B - 1], local[:B][B - 1])           # the chunk-final state (what travels to the next rank)
     # chunk 0 (clip start) needs no carry: identical to the in-order frames
     local0, out0 = eng.local_scan(frames[:B], first_index=0, clip_start=True)
     torch.cuda.synchronize()
-    assert torch.equal(out0, seq_out[:B]) and torch.equal(local0, states[:B])
+    assert torch.equal(out0, seq_out[:B]) and torch.equal(local0[:B], states[:B])
+    # a chunk LONGER than the settling time (p = 0.5: 26 frames): per-frame states only for its first 26 frames, the rest of
+    # the chunk runs with the state in registers; frames, kept states and the chunk-final state still those of the in-order render
+    from pythoncrt_amd.shard import settle_frames
+    BL, hs, ws = 40, 48, 64
+    K = settle_frames(rs.persistence, 2.0 ** -26)
+    assert K < BL
+    fl = torch.randint(0, 256, (2 * BL, hs, ws, 3), dtype=torch.uint8, generator=g).to(dev)
+    pl = FramePipeline(dev, hs, ws, rs, fps=30.0, noise_seed=12)
+    sl = torch.empty((2 * BL, hs, ws, 3), dtype=torch.float32, device=dev)
+    seq_l, _ = pl.run(fl, first_index=0, local_states=sl)
+    el = GpuShardEngine(pl, BL, slots=2)
+    assert el.keep == K and el.local[0].shape[0] == K
+    loc0, o0 = el.local_scan(fl[:BL], first_index=0, clip_start=True, slot=0)
+    loc1, o1 = el.local_scan(fl[BL:], first_index=BL, clip_start=False, slot=1)
+    el.correct(loc1[:K], sl[BL - 1].clone(), rs.persistence, o1[:K])
+    torch.cuda.synchronize()
+    assert torch.equal(o0, seq_l[:BL]) and torch.equal(loc0[:K], sl[:K]) and torch.equal(loc0[BL - 1], sl[BL - 1])
+    d = (o1.cpu().to(torch.int16) - seq_l[BL:].cpu().to(torch.int16)).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3
+    assert float((loc1[BL - 1] + (rs.persistence ** BL) * sl[BL - 1] - sl[2 * BL - 1]).abs().max()) < 5e-7
+    with pytest.raises(IndexError):
+        loc1[:K + 1]
     # one rank: ShardedRender carries the state itself from chunk to chunk — the in-order frames, bit for bit
     from pythoncrt_amd.shard import FrameShard, ShardedRender
     render = ShardedRender(FrameShard(1, 0, B), rs.persistence, GpuShardEngine(pipe, B), dist=None)
