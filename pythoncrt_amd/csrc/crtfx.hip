@@ -476,7 +476,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
             dim3 glean(grid.x, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
             launch_point_lean(c, gates == SF_FAST_PIX, k1.blend == CRTFX_BLEND_RENDER, glean, dim3(64 * waves), s, pe.e0, pe.e1, kf, k1);
         }
-        else if (!c->force_generic && !((fl & CRTFX_F_NOISE) && c->kp.grain > 1)) {      // any gate set, loads branch-free
+        else if (!c->force_generic) {      // any gate set, loads branch-free
             const bool one = !(fl & CRTFX_F_PIXELATE) && !((fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST));      // no load address depends on another load
             if (c->pix_fmt == CRTFX_PIX_F16) {
                 if (one) { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_F16, true>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
@@ -899,9 +899,9 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         {
             const uint32_t gates = fl & ~(uint32_t)CRTFX_F_WARP;
             const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
-            const bool seq_ok = !gauss && !c->split && !c->force_generic && !((fl & CRTFX_F_NOISE) && c->kp.grain > 1) &&
+            const bool seq_ok = !gauss && !c->split && !c->force_generic &&
                                 (!warp || (size_t)c->H * c->W * 12 < ((size_t)1 << 31));      // with a warp behind it: pre-warp images parked, then k_warp_lean
-            const bool lean_gates = !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full;
+            const bool lean_gates = !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
             bool lean = lean_gates;
             KGroup kg{};
             KWarpGroup wg{};                     // warp on: the frames' FINAL outputs (the point kernels then only park pre-warp images)

@@ -945,6 +945,20 @@ __global__ __launch_bounds__(1024) void k_point(KParams Pin, KFrame F, KOut O) {
     emit_pixel(P, F, O, y, x0, lane, live, M, r, g, b, lut, lut + LUT_STRIDE);
 }
 
+// a11 with grain_size > 1 for the branch-free point kernels: the pixel's N(0,1) sample = bilinear upsample (ref:637-642) of the coarse
+// plane of hashed normals (or of an injected coarse plane) from tap indices / weights the caller has already loaded.
+__device__ __forceinline__ float coarse_grain(const KParams& P, const KFrame& F, int sx, int sy, float a1, float b1) {
+    const int sx1 = min(sx + 1, P.gw - 1), sy1 = min(sy + 1, P.gh - 1);
+    const float a0 = 1.0f - a1, b0 = 1.0f - b1;
+    const uint32_t i00 = (uint32_t)sy * P.gw + sx, i01 = (uint32_t)sy * P.gw + sx1;
+    const uint32_t i10 = (uint32_t)sy1 * P.gw + sx, i11 = (uint32_t)sy1 * P.gw + sx1;
+    float n00, n01, n10, n11;
+    if (F.noise_plane) { n00 = F.noise_plane[i00]; n01 = F.noise_plane[i01]; n10 = F.noise_plane[i10]; n11 = F.noise_plane[i11]; }
+    else { n00 = grain_normal(F.key0, F.key1, i00); n01 = grain_normal(F.key0, F.key1, i01);
+           n10 = grain_normal(F.key0, F.key1, i10); n11 = grain_normal(F.key0, F.key1, i11); }
+    return (n00 * a0 + n01 * a1) * b0 + (n10 * a0 + n11 * a1) * b1;
+}
+
 // k_point_sel — the pointwise chain for ANY gate set with the loads made branch-free.  hipcc ends every conditional
 // block that contains a load with an s_waitcnt vmcnt(0), so the gate-by-gate k_point above pays one memory round trip
 // per enabled stage (eight in a row for the reference CLI's defaults with one knob changed).  Here every stage's
@@ -988,6 +1002,7 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     __shared__ float lut[2 * LUT_STRIDE];
     KParams P = Pin;
     P.pix = PIX; P.grain = 1;
+    const bool gr = (Pin.flags & CRTFX_F_NOISE) && Pin.grain > 1;       // coarse grain: the sample is formed here, not in the tail
     KOut O = Oin;
     O.pix = PIX;
     const uint32_t fl = P.flags;
@@ -1023,7 +1038,9 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     const uint32_t ov_after = *(O.overlay_after ? reinterpret_cast<const uint32_t*>(O.overlay_after) + pix : zu);
     const float* sin = O.state_in ? O.state_in : O.state;
     const F3 st = *reinterpret_cast<const F3*>((O.blend != CRTFX_BLEND_NONE) ? sin + (size_t)pix * 3 : zf);
-    const float zn = *(F.noise_plane ? F.noise_plane + pix : zf);
+    const float zn = *((F.noise_plane && !gr) ? F.noise_plane + pix : zf);
+    const int gsx = *(gr ? P.gx_ofs + x : zi), gsy = *(gr ? P.gy_ofs + y : zi);
+    const float ga1 = *(gr ? P.gx_a + x : zf), gb1 = *(gr ? P.gy_a + y : zf);
     const bool gb = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);      // split Gaussian bloom: the blurred plane in P.ds
     const F3 gbl = *reinterpret_cast<const F3*>(gb ? P.ds + (size_t)pix * 3 : zf);
     if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT))
@@ -1059,6 +1076,7 @@ __global__ __launch_bounds__(1024) void k_point_sel(KParams Pin, KFrame F, KOut 
     }
     if (gb) { r = clip01(r + P.bloom_strength * gbl.x); g = clip01(g + P.bloom_strength * gbl.y); b = clip01(b + P.bloom_strength * gbl.z); }   // ref:611
     PixMasks M{tm.x, tm.y, tm.z, sl, vfull ? vfv : vignette_gain(P, nx2, ny2), zn, F.noise_plane != nullptr};
+    if (gr) { M.z = coarse_grain(P, F, gsx, gsy, ga1, gb1); M.has_z = 1; }
     if (promotes(P)) point_finish<double>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
     else point_finish<float>(P, F, O, y, x, pix, row_live, M, r, g, b, lut, ov_after, st, x0, lane);
 }
@@ -1072,6 +1090,7 @@ __global__ __launch_bounds__(1024) void k_point_sel_seq(KParams Pin, KGroup G, i
     __shared__ float lut[2 * LUT_STRIDE];
     KParams P = Pin;
     P.pix = PIX; P.grain = 1;
+    const bool gr = (Pin.flags & CRTFX_F_NOISE) && Pin.grain > 1;       // coarse grain: the sample is formed here, not in the tail
     const uint32_t fl = P.flags;
     const float* ones = P.consts;
     const float* zf = P.consts + 4;
@@ -1102,6 +1121,8 @@ __global__ __launch_bounds__(1024) void k_point_sel_seq(KParams Pin, KGroup G, i
     const bool vg = (fl & CRTFX_F_VIGNETTE) != 0, vfull = vg && P.vig_full != nullptr;
     const double vfv = *(vfull ? P.vig_full + pix : zd);
     const double nx2 = *((vg && !vfull) ? P.vig_nx2 + x : zd), ny2 = *((vg && !vfull) ? P.vig_ny2 + y : zd);
+    const int gsx = *(gr ? P.gx_ofs + x : zi), gsy = *(gr ? P.gy_ofs + y : zi);
+    const float ga1 = *(gr ? P.gx_a + x : zf), gb1 = *(gr ? P.gy_a + y : zf);
     const KOut O0 = G.o[0];
     const float* sin0 = O0.state_in ? O0.state_in : O0.state;
     F3 st = *reinterpret_cast<const F3*>((O0.blend != CRTFX_BLEND_NONE) ? sin0 + (size_t)pix * 3 : zf);
@@ -1124,7 +1145,7 @@ __global__ __launch_bounds__(1024) void k_point_sel_seq(KParams Pin, KGroup G, i
         const float sl = *((fl & CRTFX_F_SCANLINES) ? (F.scan_plane ? F.scan_plane + pix : F.scan_row + y) : ones);
         const uint32_t ov_before = *(F.overlay_before ? reinterpret_cast<const uint32_t*>(F.overlay_before) + pix : zu);
         const uint32_t ov_after = *(O.overlay_after ? reinterpret_cast<const uint32_t*>(O.overlay_after) + pix : zu);
-        const float zn = *(F.noise_plane ? F.noise_plane + pix : zf);
+        const float zn = *((F.noise_plane && !gr) ? F.noise_plane + pix : zf);
         const RawRGB raw = load_raw(PIX, F.in, row + (uint32_t)xr * 3u, row + (uint32_t)xs * 3u + 1u, row + (uint32_t)xb * 3u + 2u);
         F3 p00{0, 0, 0}, p01{0, 0, 0}, p10{0, 0, 0}, p11{0, 0, 0};
         if constexpr (!ONE) {
@@ -1147,6 +1168,7 @@ __global__ __launch_bounds__(1024) void k_point_sel_seq(KParams Pin, KGroup G, i
             r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
         }
         PixMasks M{tm.x, tm.y, tm.z, sl, vgain, zn, F.noise_plane != nullptr};
+        if (gr) { M.z = coarse_grain(P, F, gsx, gsy, ga1, gb1); M.has_z = 1; }
         KOut Ow = O;
         if (!keep_state) Ow.state = nullptr;       // the next frame of the run takes the state from this thread's registers
         F3 fin;
