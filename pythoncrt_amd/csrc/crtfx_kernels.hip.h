@@ -1281,7 +1281,8 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
     const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
     using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
     int yr[ROWS];
-    uint32_t o00[ROWS], o01[ROWS], o10[ROWS], o11[ROWS];      // float offsets of the four half-res taps inside a slot
+    uint32_t o00[ROWS], o01[ROWS], o10[ROWS], o11[ROWS];      // BYTE offsets of the four half-res taps inside a slot (32-bit: the loads take scalar base + vector offset)
+    uint32_t er[ROWS], eg[ROWS], eb[ROWS];                    // element offsets of the pixel's three samples inside a frame (pixelate map and aberration wrap resolved once)
     float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
     F3 st[ROWS];
     PixMasks M0[ROWS];                           // triad mask and vignette gain of the pixel: frame-invariant (the scanline gain is not)
@@ -1298,8 +1299,16 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
             const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
             const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
             a1[k] = P.ux_a[x]; a0[k] = 1.0f - a1[k]; b1[k] = P.uy_a[y]; b0[k] = 1.0f - b1[k];
-            o00[k] = (uint32_t)(sy * P.hw + sx) * 3u; o01[k] = (uint32_t)(sy * P.hw + sx1) * 3u;
-            o10[k] = (uint32_t)(sy1 * P.hw + sx) * 3u; o11[k] = (uint32_t)(sy1 * P.hw + sx1) * 3u;
+            o00[k] = (uint32_t)(sy * P.hw + sx) * 12u; o01[k] = (uint32_t)(sy * P.hw + sx1) * 12u;
+            o10[k] = (uint32_t)(sy1 * P.hw + sx) * 12u; o11[k] = (uint32_t)(sy1 * P.hw + sx1) * 12u;
+        }
+        {   // = fetch_raw's addressing (ref:573-583), frame-invariant
+            int xs = x, ys = y;
+            if constexpr ((SF & CRTFX_F_PIXELATE) != 0) { xs = P.xmap[x]; ys = P.ymap[y]; }
+            const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
+            int xr = xs, xb = xs;
+            if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }
+            er[k] = row + (uint32_t)xr * 3u; eg[k] = row + (uint32_t)xs * 3u + 1u; eb[k] = row + (uint32_t)xb * 3u + 2u;
         }
         if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
@@ -1318,12 +1327,17 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
             PixMasks M = M0[k];
             if constexpr ((SF & CRTFX_F_SCANLINES) != 0) M.sl = F.scan_row[y];
             float r, g, b;
-            fetch_graded(P, F, y, x, r, g, b);
+            {   // = fetch_graded (no overlay in the lean build)
+                const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
+                if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+                else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+            }
             if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
-                const F3 p00 = *reinterpret_cast<const F3*>(ds + o00[k]);
-                const F3 p01 = *reinterpret_cast<const F3*>(ds + o01[k]);
-                const F3 p10 = *reinterpret_cast<const F3*>(ds + o10[k]);
-                const F3 p11 = *reinterpret_cast<const F3*>(ds + o11[k]);
+                const char* dsb = reinterpret_cast<const char*>(ds);
+                const F3 p00 = *reinterpret_cast<const F3*>(dsb + o00[k]);
+                const F3 p01 = *reinterpret_cast<const F3*>(dsb + o01[k]);
+                const F3 p10 = *reinterpret_cast<const F3*>(dsb + o10[k]);
+                const F3 p11 = *reinterpret_cast<const F3*>(dsb + o11[k]);
                 const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
                 const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
                 const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
