@@ -41,7 +41,12 @@ def test_random_render_matches_oracle(case):
     n, first, fps, seed = 6, int(rng.integers(0, 50)), 25.0, int(rng.integers(1 << 40))      # 6 frames: a full 4-frame persistence run behind frame 0, then a partial one
     frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     dev = torch.device("cuda", torch.cuda.current_device())
-    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed)
+    ov_mode = int(rng.integers(4))              # 0, 1: no text overlay; 2: blended before the effects; 3: after them (ref:588-598 / 653-663)
+    ov = None
+    if ov_mode >= 2:
+        ov = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        ov[..., 3] = np.where(rng.random((h, w)) < 0.5, 0, ov[..., 3])      # half the plane untouched, the rest any alpha
+    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed, text_overlay_rgba=ov, text_overlay_after=(ov_mode == 3))
     out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
     # the grain the kernels drew, exported for the oracle (cv2.randn is unreproducible)
     gh, gw = (h, w) if rs.grain_size <= 1 else (max(1, h // rs.grain_size), max(1, w // rs.grain_size))
@@ -60,6 +65,8 @@ def test_random_render_matches_oracle(case):
         "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "glitch_amp_px", "glitch_height_frac", "brightness", "contrast",
         "gamma", "saturation", "temperature", "flicker_strength", "flicker_hz", "grain_size", "scanline_angle", "scanline_thickness",
         "warp_strength")}
+    if ov is not None:
+        params["text_overlay_rgba"], params["text_overlay_after"] = ov, ov_mode == 3
     exp, exp_state = orc.process_frames(list(frames), params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
                                         rs.triad_softness, rs.vignette_strength, noise_planes=planes, first_index=first)
     got = out.cpu().numpy()
