@@ -104,8 +104,9 @@ def source_hash():
     sha1 over the kernel sources, so that a stale traffic figure is never attached to a different build."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("pythoncrt_amd/csrc/crtfx_kernels.hip.h", "pythoncrt_amd/csrc/crtfx.hip", "pythoncrt_amd/csrc/crtfx_rr.hip",
-              "pythoncrt_amd/csrc/crtfx_internal.h", "include/crtfx.h"):
+    for f in ("pythoncrt_amd/csrc/crtfx_kernels.hip.h", "pythoncrt_amd/csrc/crtfx_common.hip.h", "pythoncrt_amd/csrc/crtfx_blur.hip.h",
+              "pythoncrt_amd/csrc/crtfx_point.hip.h", "pythoncrt_amd/csrc/crtfx_phosphor.hip.h", "pythoncrt_amd/csrc/crtfx_warp.hip.h",
+              "pythoncrt_amd/csrc/crtfx.hip", "pythoncrt_amd/csrc/crtfx_rr.hip", "pythoncrt_amd/csrc/crtfx_internal.h", "include/crtfx.h"):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -27,7 +27,7 @@ struct DevBuf {
 }  // namespace
 
 // Gaussian bloom radii from here on run the split path (three blur kernels + the pointwise chain) instead of a fused
-// register-window build: see k_sb_rows in crtfx_kernels.hip.h and profiles/r02_sigma_sweep.txt for the crossover.
+// register-window build: see k_sb_rows in crtfx_blur.hip.h and profiles/r02_sigma_sweep.txt for the crossover.
 constexpr int SPLIT_FROM_RADIUS = 31;
 constexpr int SPLIT_MAX_RADIUS = 1 << 16;     // sigma ~ 21845: far beyond any frame size; a sanity bound on the tap array only
 
