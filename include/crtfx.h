@@ -70,7 +70,7 @@ typedef struct crtfx_params {
     uint32_t flags;              /* CRTFX_F_* */
     int32_t  aberration_px;      /* ref:571-577: R from x-d, B from x+d, wrap-around */
     int32_t  grain_size;         /* ref:637 (1 = per-pixel grain) */
-    int32_t  bloom_radius;       /* (ksize-1)/2 with ksize = max(1, round(3 sigma)*2+1)  ref:609 */
+    int32_t  bloom_radius;       /* (ksize-1)/2 with ksize = max(1, round(3 sigma)*2+1)  ref:609; any radius in [0, 65536] (the reference takes any sigma) */
     int32_t  reserved0;
     float    saturation;         /* ref:290 */
     float    r_gain, b_gain;     /* clip(1 +/- 0.5 t, 0.5, 1.5)  ref:294-295 */
