@@ -292,21 +292,24 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     }();
     (void)table_ready;
     const int R = c->kp.R;          // the BUILD radius (crtfx_set_params pads the taps of a bucketed radius)
-    bool folded = (c->kp.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags;
+    const uint32_t gates = c->kp.flags & ~(uint32_t)CRTFX_F_WARP;
+    // the full-chain gate set, and (uint8 frames) the same with pixelate — the reference CLI's default pixel size is 2 — have gate-folded builds
+    const bool pix_fold = gates == (SF_FULL | CRTFX_F_PIXELATE) && c->pix_fmt == CRTFX_PIX_U8;
+    bool folded = (gates == SF_FULL || pix_fold) && !c->force_runtime_flags;
     if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
     for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
     // the column-owner kernel takes the full-chain launches that park a pre-warp image (warp and / or persistence behind them)
     // — for uint8 frames and radii >= CC_MIN_RADIUS, where it is the faster build (4K, R = 9: 134 vs 140 us per 2-frame launch;
     // R = 5 / 6 / 7 within 1-3 % the other way; 1080p, R = 4: 64 vs 60; 8K half frames: 288 vs 284: profiles/r02_cc_ab.txt).  Its stores address a frame's scratch
     // image with 32-bit byte offsets.
-    bool cc = folded && !c->no_cc && use_cc(c, R);
+    bool cc = folded && !pix_fold && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
     int& seg_slot = c->seg_for[cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, cc).seg;   // planned once per (kernel build, group size)
     const int seg = seg_slot;
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const int variant = cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? 1 : 0));
+    const int variant = cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
     const bool runtime = !folded;
     const size_t lds = cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
                           : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
@@ -681,9 +684,11 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         // 4K with 4 frames per grid = 398 MB and k_warp goes from 38 to 44 us per frame)
         int gcap = (int)(((size_t)224 << 20) / ((size_t)H * W * 3 * sizeof(float)));
         gcap = gcap < 1 ? 1 : (gcap > MAX_GROUP ? MAX_GROUP : gcap);
-        const bool folded_plan = (k.flags & ~(uint32_t)CRTFX_F_WARP) == SF_FULL && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
+        const uint32_t gates_plan = k.flags & ~(uint32_t)CRTFX_F_WARP;
+        const bool pix_fold_plan = gates_plan == (SF_FULL | CRTFX_F_PIXELATE) && c->pix_fmt == CRTFX_PIX_U8;
+        const bool folded_plan = (gates_plan == SF_FULL || pix_fold_plan) && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
-        const bool cc_plan = folded_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
+        const bool cc_plan = folded_plan && !pix_fold_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_plan);
         if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) { gp.g = c->opt_group; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, gp.g); }
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;

@@ -263,8 +263,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     uint32_t* rowtab = cring + rr_cring_floats(R, PIX, SF == 0xFFFFFFFFu);                              // [16][5] ring: scan gain bits, ny2 lo, ny2 hi, grain row offset, grain row weight of output row y at (y - y_begin) & 15
     int* ytab = reinterpret_cast<int*>(rowtab + 16 * 5);
     constexpr bool NLUT = (SF != 0xFFFFFFFFu) && PIX == 0;                 // gate-folded uint8 build: a1 from a 256-entry LDS table
-    float* nlut = reinterpret_cast<float*>(ytab);                          // (that build never pixelates: ytab is empty)
-    float* glut = reinterpret_cast<float*>(ytab + ((Pin.flags & CRTFX_F_PIXELATE) ? seg_rows + 2 * R : 0));   // [3][256] grade table (runtime-gate build)                   // [seg_rows + 2R]: source row of halo row (pixelate)
+    const int ytab_rows = (P.flags & CRTFX_F_PIXELATE) ? seg_rows + 2 * R : 0;      // [seg_rows + 2R]: source row of halo row (pixelate)
+    float* nlut = reinterpret_cast<float*>(ytab + ytab_rows);              // [256] behind the pixelate row map (empty without pixelate); gate-folded uint8 builds
+    float* glut = reinterpret_cast<float*>(ytab + ytab_rows);              // [3][256] grade table (runtime-gate build: it has no a1 table)
 
     // The four waves of a block have unequal roles (the V-pass has 192 columns for 256 threads, wave 0 carries the
     // prefetches).  Rotating the roles by the block's dispatch number spreads them over the SIMDs of a CU: measured

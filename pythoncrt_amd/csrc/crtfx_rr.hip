@@ -4,7 +4,7 @@
 #include "crtfx_internal.h"
 
 #ifndef RR_R
-#error "compile with -DRR_R=<radius 1..30, or a bucket radius 36 / 42 / 48 / 64 / 80 / 96 / 112 / 128>"
+#error "compile with -DRR_R=<radius 1..30>"
 #endif
 
 namespace crtfx {
@@ -14,7 +14,7 @@ namespace crtfx {
 
 void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_rows, dim3 grid, size_t lds,
                                  hipStream_t s, int variant, hipEvent_t e0, hipEvent_t e1) {
-    // radius buckets (RR_R > 30) park more than 64 KiB of LDS in every build: opt in once per kernel and device
+    // a build that parks more than 64 KiB of LDS opts in once per kernel and device (none of the radii 1..30 does today)
 #define CRTFX_BIG_LDS(kern)                                                                                              \
     do {                                                                                                                  \
         if (lds > 65536) {                                                                                                \
@@ -33,6 +33,10 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         return;
     }
 #endif
+    if (variant == 5) {     // uint8 frames, full-chain gates + pixelate (the reference CLI's default pixel size 2 with --no-fast-bloom)
+        CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL | CRTFX_F_PIXELATE, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+        return;
+    }
     if (variant == 2) {     // half frames, full-chain gates
         CRTFX_BIG_LDS((k_phosphor_rr<RR_R, SF_FULL, 1>));
         CRTFX_LAUNCH((k_phosphor_rr<RR_R, SF_FULL, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
