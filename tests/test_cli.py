@@ -42,3 +42,41 @@ def test_clamps_match_reference_main():
             if k in RENAME:
                 continue
             assert getattr(rs, k) == v, (name, k, getattr(rs, k), v)
+
+
+def test_positional_file_io_helpers(tmp_path, monkeypatch):
+    """cli._pread_full / _pwrite_full: sliced, threaded positional I/O equals one plain read / write — offsets, a short file, sizes that
+    are not a multiple of the slice."""
+    import numpy as np
+    monkeypatch.setattr(cli, "_IO_SLICE", 1000)                      # many slices on a small file
+    data = np.random.default_rng(5).integers(0, 256, 12345, dtype=np.uint8).tobytes()
+    src = tmp_path / "src.bin"
+    src.write_bytes(data)
+    fd = os.open(src, os.O_RDONLY)
+    try:
+        buf = bytearray(5000)
+        assert cli._pread_full(fd, memoryview(buf), 2345) == 5000 and bytes(buf) == data[2345:7345]
+        buf = bytearray(4000)                                        # runs past the end of the file: the contiguous prefix only
+        got = cli._pread_full(fd, memoryview(buf), 10000)
+        assert got == 2345 and bytes(buf[:got]) == data[10000:]
+        buf = bytearray(300)                                         # a single slice
+        assert cli._pread_full(fd, memoryview(buf), 0) == 300 and bytes(buf) == data[:300]
+    finally:
+        os.close(fd)
+    dst = tmp_path / "dst.bin"
+    fd = os.open(dst, os.O_WRONLY | os.O_CREAT)
+    try:
+        cli._pwrite_full(fd, memoryview(data)[:7000], 0)
+        cli._pwrite_full(fd, memoryview(data)[7000:], 7000)
+        cli._pwrite_full(fd, memoryview(b""), 0)
+    finally:
+        os.close(fd)
+    assert dst.read_bytes() == data
+    with open(src, "rb") as f:
+        assert cli._seekable(f)
+    r, w = os.pipe()
+    try:
+        with os.fdopen(r, "rb") as pr:
+            assert not cli._seekable(pr)
+    finally:
+        os.close(w)
