@@ -177,3 +177,19 @@ def test_shared_scanline_table_for_integer_phases():
         rows = tables.scanline_rows(h, strength, period, phases)
         g = tables.scanline_rows_at(np.arange(100, 139 + h, dtype=np.float32), strength, period)
         assert g.dtype == np.float32 and all(np.array_equal(rows[b], g[b:b + h]) for b in range(len(phases)))
+
+
+def test_local_states_view():
+    """pipeline._LocalStates: what ShardedRender indexes of a chunk's local states (first k frames + the chunk-final one)."""
+    import torch
+    from pythoncrt_amd.pipeline import _LocalStates
+    first = torch.arange(3 * 2 * 2 * 3, dtype=torch.float32).view(3, 2, 2, 3)
+    final = torch.full((2, 2, 3), -1.0)
+    ls = _LocalStates(first, final, n=10)
+    assert ls.shape == (10, 2, 2, 3)
+    assert ls[9] is final and ls[-1] is final and torch.equal(ls[1], first[1])
+    assert torch.equal(ls[:2], first[:2]) and torch.equal(ls[:3], first)
+    with pytest.raises(IndexError):
+        ls[:4]
+    with pytest.raises(IndexError):
+        ls[1:3]
