@@ -690,7 +690,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
         const bool cc_plan = folded_plan && !pix_fold_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_plan);
-        if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) { gp.g = c->opt_group; gp.seg = pick_seg_rows(H, W, R, c->pix_fmt, gp.g); }
+        if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, c->opt_group, c->opt_group, cc_plan);      // the planner's rows per block for the group size asked for
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;
         const int need = c->overlap ? 2 * gp.g : gp.g;
         if (need > c->pre_frames) {
