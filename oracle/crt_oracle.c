@@ -297,6 +297,60 @@ int orc_resize_linear_f32(const float* src, int sh, int sw, float* dst, int dh, 
     return 0;
 }
 
+/* ALTERNATIVE FORM of the same resize (not the oracle: the spread around it, see orc_sepblur_f32_variant): mode 1 = the two
+ * linear passes with a fused multiply-add (an FMA build contracts S0*a0 + S1*a1), and the 2x2 mean of the exact-decimation
+ * fast path summed pairwise, (p00 + p01) + (p10 + p11), as a SIMD resizeAreaFast adds its row vectors. */
+int orc_resize_linear_f32_variant(const float* src, int sh, int sw, float* dst, int dh, int dw, int cn, int mode)
+{
+    if (dw * 2 == sw && dh * 2 == sh) {
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < cn; ++c) {
+                    const float* p = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c;
+                    const float* q = p + (size_t)sw * cn;
+                    dst[((size_t)y * dw + x) * cn + c] = mode ? ((p[0] + p[cn]) + (q[0] + q[cn])) * 0.25f : (p[0] + p[cn] + q[0] + q[cn]) * 0.25f;
+                }
+        return 0;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    float* xa = (float*)malloc(sizeof(float) * dw);
+    float* rows = (float*)malloc(sizeof(float) * 2 * (size_t)dw * cn);
+    if (!xofs || !xa || !rows) { free(xofs); free(xa); free(rows); return -1; }
+    for (int x = 0; x < dw; ++x) {
+        float fx = (float)((x + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[x] = sx; xa[x] = fx;
+    }
+    for (int y = 0; y < dh; ++y) {
+        float fy = (float)((y + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+        int sy1 = sy + 1 < sh ? sy + 1 : sh - 1;
+        for (int r = 0; r < 2; ++r) {
+            const float* srow = src + (size_t)(r ? sy1 : sy) * sw * cn;
+            float* rr = rows + (size_t)r * dw * cn;
+            for (int x = 0; x < dw; ++x) {
+                int sx = xofs[x];
+                int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+                float a1 = xa[x], a0 = 1.0f - a1;
+                for (int c = 0; c < cn; ++c)
+                    rr[(size_t)x * cn + c] = mode ? fmaf(srow[(size_t)sx1 * cn + c], a1, srow[(size_t)sx * cn + c] * a0) : srow[(size_t)sx * cn + c] * a0 + srow[(size_t)sx1 * cn + c] * a1;
+            }
+        }
+        const float b1 = fy, b0 = 1.0f - fy;
+        float* drow = dst + (size_t)y * dw * cn;
+        for (size_t i = 0; i < (size_t)dw * cn; ++i) drow[i] = mode ? fmaf(rows[(size_t)dw * cn + i], b1, rows[i] * b0) : rows[i] * b0 + rows[(size_t)dw * cn + i] * b1;
+    }
+    free(xofs); free(xa); free(rows);
+    return 0;
+}
+
 /* cv2.resize INTER_LINEAR for CV_64F (the persistence state of a promoted chain, ref:690): same
  * offsets and FLOAT coefficients as the 32F path (the alpha/beta tables are float for every depth),
  * arithmetic in double (HResizeLinear<double,double,float>, VResizeLinear<double,double,float>);
@@ -388,4 +442,4 @@ int orc_add_weighted_f64(const double* a, double alpha, const double* b, double 
     return 0;
 }
 
-int orc_abi_version(void) { return 2; }
+int orc_abi_version(void) { return 3; }

@@ -60,6 +60,7 @@ def _lib():
     lib.orc_remap_bilinear_f64.argtypes = [dp, dp, ci, ci, ci, fp, fp]
     lib.orc_resize_nearest_f32.argtypes = [fp, ci, ci, fp, ci, ci, ci]
     lib.orc_resize_linear_f32.argtypes = [fp, ci, ci, fp, ci, ci, ci]
+    lib.orc_resize_linear_f32_variant.argtypes = [fp, ci, ci, fp, ci, ci, ci, ci]
     lib.orc_resize_linear_f64.argtypes = [dp, ci, ci, dp, ci, ci, ci]
     lib.orc_convert_scale_abs_f32.argtypes = [fp, up, ctypes.c_size_t, ctypes.c_float]
     lib.orc_convert_scale_abs_f64.argtypes = [dp, up, ctypes.c_size_t, ctypes.c_float]
@@ -75,8 +76,9 @@ def _lib():
 # Which restated OpenCV accumulation form the cv2 stand-ins below use.  The ORACLE is the default (all zeros); tests
 # switch the other forms in through `opencv_variant` to measure the spread around it (crt_oracle.c, "ALTERNATIVE
 # ACCUMULATION FORMS").  blur_row / blur_col: modes of orc_sepblur_f32_variant; remap_fma: contracted bilinear sum for
-# CV_64F images; csa_double: convertScaleAbs of a CV_64F image multiplied in double (scalar tail of cvtabs_32f).
-VARIANT = {"blur_row": 0, "blur_col": 0, "remap_fma": 0, "csa_double": 0}
+# CV_64F images; csa_double: convertScaleAbs of a CV_64F image multiplied in double (scalar tail of cvtabs_32f);
+# resize_fma: the INTER_LINEAR passes contracted, the exact-2x mean summed pairwise (fast bloom, grain upsample).
+VARIANT = {"blur_row": 0, "blur_col": 0, "remap_fma": 0, "csa_double": 0, "resize_fma": 0}
 OPENCV_VARIANTS = {
     "oracle (RowFilter fma | ColumnFilter fma)": {},
     "SymmColumnFilter fma": {"blur_col": 1},
@@ -86,7 +88,8 @@ OPENCV_VARIANTS = {
     "SymmRowSmall + SymmColumn mul+add": {"blur_row": 3, "blur_col": 2},
     "remap contracted (fma)": {"remap_fma": 1},
     "convertScaleAbs in double": {"csa_double": 1},
-    "all alternatives at once": {"blur_row": 3, "blur_col": 2, "remap_fma": 1, "csa_double": 1},
+    "resize contracted (fma), pairwise 2x2 mean": {"resize_fma": 1},
+    "all alternatives at once": {"blur_row": 3, "blur_col": 2, "remap_fma": 1, "csa_double": 1, "resize_fma": 1},
 }
 
 
@@ -240,7 +243,10 @@ def resize(img: np.ndarray, dsize: Tuple[int, int], interpolation: str) -> np.nd
     if interpolation == "nearest":
         _lib().orc_resize_nearest_f32(_fp(src), sh, sw, _fp(dst), dh, dw, cn)
     elif interpolation == "linear":
-        rc = _lib().orc_resize_linear_f32(_fp(src), sh, sw, _fp(dst), dh, dw, cn)
+        if VARIANT["resize_fma"]:
+            rc = _lib().orc_resize_linear_f32_variant(_fp(src), sh, sw, _fp(dst), dh, dw, cn, 1)
+        else:
+            rc = _lib().orc_resize_linear_f32(_fp(src), sh, sw, _fp(dst), dh, dw, cn)
         assert rc == 0
     else:
         raise ValueError(interpolation)

@@ -35,7 +35,7 @@ def test_variant_zero_is_the_oracle():
     src = np.random.default_rng(0).random((40, 50, 3), dtype=np.float32)
     a = orc.gaussian_blur(src, (19, 19), 3.0, 3.0)
     with orc.opencv_variant(blur_row=0, blur_col=0):
-        assert orc.VARIANT == {"blur_row": 0, "blur_col": 0, "remap_fma": 0, "csa_double": 0}
+        assert orc.VARIANT == {"blur_row": 0, "blur_col": 0, "remap_fma": 0, "csa_double": 0, "resize_fma": 0}
     kx = orc.gaussian_kernel(19, 3.0)
     d, t = np.empty_like(src), np.empty_like(src)
     orc._lib().orc_sepblur_f32_variant(orc._fp(src), orc._fp(d), orc._fp(t), 40, 50, 3, orc._fp(kx), 19, orc._fp(kx), 19, 0, 0)
@@ -70,3 +70,37 @@ def test_chain_spread_on_baseline_configs(cfg, warp):
         du = np.abs(u.astype(np.int16) - u0.astype(np.int16))
         assert d.max() <= FLOAT_STEP and (d > 1e-6).mean() < FRAC, (name, float(d.max()), float((d > 1e-6).mean()))
         assert du.max() <= 1 and (du != 0).mean() < FRAC, (name, int(du.max()), float((du != 0).mean()))
+
+
+def fast_chain(f, plane, pixel_size, grain_size=1):
+    """The reference CLI's default chain: fast half-res bloom (two cv2.resize INTER_LINEAR, ref:605-607), pixelate."""
+    tm, vg = orc.make_triad_mask(H, W, 0.35, 0.5), orc.make_vignette(H, W, 0.25)
+    return orc.apply_crt_effect(f, 0.6, tm, 2.2, False, 1, 1.2, 0.25, 0.0, 1.5, vg, 0.0, None, 2.0, 1.25, True, pixel_size,
+                                noise_plane=plane, grain_size=grain_size)
+
+
+def test_resize_forms_stay_within_a_few_ulp():
+    rng = np.random.default_rng(3)
+    for (sh, sw, dh, dw) in ((68, 120, 135, 240), (135, 240, 67, 120), (64, 80, 32, 40), (33, 47, 90, 101)):
+        src = rng.random((sh, sw, 3), dtype=np.float32)
+        ref = orc.resize(src, (dw, dh), "linear")
+        with orc.opencv_variant(resize_fma=1):
+            got = orc.resize(src, (dw, dh), "linear")
+        ulp = int(np.abs(ref.view(np.int32).astype(np.int64) - got.view(np.int32).astype(np.int64)).max())
+        assert ulp <= 4, ((sh, sw, dh, dw), ulp)          # measured: 1 .. 3
+
+
+@pytest.mark.parametrize("pixel_size,grain_size", [(2, 1), (1, 1), (1, 2)])
+def test_fast_bloom_chain_spread(pixel_size, grain_size):
+    """cv2.resize is unpinned too: the contracted / pairwise forms of its two linear passes move the fast-bloom chain by at most
+    one LUT step on < 1e-4 of the samples and the uint8 frame by 1 LSB on < 1e-4 of them (measured: a few 1e-5)."""
+    f = frame(6)
+    gh, gw = (H, W) if grain_size <= 1 else (H // grain_size, W // grain_size)
+    plane = np.random.default_rng(10).standard_normal((gh, gw), dtype=np.float32)
+    u0, i0 = fast_chain(f, plane, pixel_size, grain_size)
+    with orc.opencv_variant(resize_fma=1):
+        u, i = fast_chain(f, plane, pixel_size, grain_size)
+    d = np.abs(i.astype(np.float64) - i0.astype(np.float64))
+    du = np.abs(u.astype(np.int16) - u0.astype(np.int16))
+    assert d.max() <= FLOAT_STEP and (d > 1e-6).mean() < FRAC, (float(d.max()), float((d > 1e-6).mean()))
+    assert du.max() <= 1 and (du != 0).mean() < FRAC, (int(du.max()), float((du != 0).mean()))
