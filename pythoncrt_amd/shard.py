@@ -106,6 +106,13 @@ class ShardedRender:
         self.overlap = bool(overlap) and self.parallel_hop and shard.world > 1
         self.timing = bool(timing)
         self._worker = None           # staged (gloo + device tensors) overlapped hops run on one worker thread
+        # gloo moves one message over ONE TCP pair (~4 GB/s of loopback memcpy): the staged hop of an overlapped schedule
+        # splits the state frame over a few extra process groups = a few sockets and gloo threads in parallel.  (RCCL: unused.)
+        self._channels = []
+        if self.overlap and dist is not None and dist.get_backend(group) == "gloo":
+            import os
+            for _ in range(max(0, min(8, int(os.environ.get("CRTFX_GLOO_CHANNELS", "4"))) - 1)):
+                self._channels.append(dist.new_group(backend="gloo"))      # collective: every rank constructs its ShardedRender
         self._last_transport_s = None
         self._pending = None          # overlapped mode: the round whose hop is in flight
         self._marks = []              # timing: per finished round (scan events, hop-wait events + host seconds, fix-up events)
@@ -145,20 +152,32 @@ class ShardedRender:
         host_send = torch.empty(recv_like.shape, dtype=recv_like.dtype, pin_memory=True) if (dst is not None and send is not None) else None
         host_recv = torch.empty(recv_like.shape, dtype=recv_like.dtype, pin_memory=True) if src is not None else None
 
+        chans = [group] + list(self._channels)
+
         def job():
             import time as _t
             t0 = _t.perf_counter()
-            ops = []
             if host_send is not None:
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
                     host_send.copy_(send, non_blocking=True)
                 side.synchronize()
-                ops.append(d.P2POp(d.isend, host_send, dst, group))
-            if host_recv is not None:
-                ops.append(d.P2POp(d.irecv, host_recv, src, group))
             t1 = _t.perf_counter()
-            for w in (d.batch_isend_irecv(ops) if ops else []):
+            works = []
+            nch = len(chans)
+            fs = host_send.view(-1) if host_send is not None else None
+            fr = host_recv.view(-1) if host_recv is not None else None
+            n_el = (fs if fs is not None else fr).numel() if (fs is not None or fr is not None) else 0
+            step = (n_el + nch - 1) // nch if n_el else 0
+            for k, g in enumerate(chans):                    # slice k of the frame travels on channel k
+                lo, hi = k * step, min(n_el, (k + 1) * step)
+                if hi <= lo:
+                    continue
+                if fs is not None:
+                    works.append(d.isend(fs[lo:hi], dst, group=g))
+                if fr is not None:
+                    works.append(d.irecv(fr[lo:hi], src, group=g))
+            for w in works:
                 w.wait()
             return host_recv, _t.perf_counter() - t1, t1 - t0
         box, done = [], threading.Event()
