@@ -111,7 +111,7 @@ class ShardedRender:
         self._channels = []
         if self.overlap and dist is not None and dist.get_backend(group) == "gloo":
             import os
-            for _ in range(max(0, min(8, int(os.environ.get("CRTFX_GLOO_CHANNELS", "4"))) - 1)):
+            for _ in range(max(0, min(8, int(os.environ.get("CRTFX_GLOO_CHANNELS", "8"))) - 1)):
                 self._channels.append(dist.new_group(backend="gloo"))      # collective: every rank constructs its ShardedRender
         self._last_transport_s = None
         self._pending = None          # overlapped mode: the round whose hop is in flight
@@ -155,31 +155,51 @@ class ShardedRender:
         chans = [group] + list(self._channels)
 
         def job():
+            # slice k of the frame travels on channel k, and the three legs are pipelined slice by slice: device -> pinned host
+            # on the side stream, the socket, pinned host -> device on the side stream again (one slice's copy under the next
+            # slice's transfer: the chain costs the transfer + one slice's copies instead of the sum of the three)
             import time as _t
             t0 = _t.perf_counter()
-            if host_send is not None:
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    host_send.copy_(send, non_blocking=True)
-                side.synchronize()
-            t1 = _t.perf_counter()
-            works = []
             nch = len(chans)
             fs = host_send.view(-1) if host_send is not None else None
             fr = host_recv.view(-1) if host_recv is not None else None
             n_el = (fs if fs is not None else fr).numel() if (fs is not None or fr is not None) else 0
             step = (n_el + nch - 1) // nch if n_el else 0
-            for k, g in enumerate(chans):                    # slice k of the frame travels on channel k
-                lo, hi = k * step, min(n_el, (k + 1) * step)
-                if hi <= lo:
-                    continue
-                if fs is not None:
-                    works.append(d.isend(fs[lo:hi], dst, group=g))
-                if fr is not None:
-                    works.append(d.irecv(fr[lo:hi], src, group=g))
-            for w in works:
+            spans = [(k * step, min(n_el, (k + 1) * step)) for k in range(nch) if min(n_el, (k + 1) * step) > k * step]
+            recvs = [d.irecv(fr[lo:hi], src, group=chans[k]) for k, (lo, hi) in enumerate(spans)] if fr is not None else []
+            staged = []
+            if fs is not None:
+                flat_dev = send.reshape(-1)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    for lo, hi in spans:
+                        fs[lo:hi].copy_(flat_dev[lo:hi], non_blocking=True)
+                        e = torch.cuda.Event()
+                        e.record(side)
+                        staged.append(e)
+            t1 = _t.perf_counter()
+            sends = []
+            for k, e in enumerate(staged):
+                e.synchronize()
+                if k == 0:
+                    t1 = _t.perf_counter()              # the scan has finished and the first slice is on the host: the transfer starts
+                lo, hi = spans[k]
+                sends.append(d.isend(fs[lo:hi], dst, group=chans[k]))
+            dev_recv, landed = None, None
+            if fr is not None:
+                with torch.cuda.stream(side):
+                    dev_recv = torch.empty(recv_like.shape, dtype=recv_like.dtype, device=recv_like.device)
+                flat_out = dev_recv.view(-1)
+                for k, w in enumerate(recvs):
+                    w.wait()
+                    lo, hi = spans[k]
+                    with torch.cuda.stream(side):
+                        flat_out[lo:hi].copy_(fr[lo:hi], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(side)
+            for w in sends:
                 w.wait()
-            return host_recv, _t.perf_counter() - t1, t1 - t0
+            return (dev_recv, landed, host_recv, host_send), _t.perf_counter() - t1, t1 - t0
         box, done = [], threading.Event()
         self._jobs.put((job, box, done))
         return ("async", box, done)
@@ -204,9 +224,14 @@ class ShardedRender:
             res = box[0]
             if isinstance(res, BaseException):
                 raise res
-            host_recv, transport_s, stage_s = res
+            (dev_recv, landed, _keep_r, _keep_s), transport_s, stage_s = res
             self._last_transport_s = transport_s
-            return host_recv.to(device, non_blocking=True) if host_recv is not None else None
+            if dev_recv is None:
+                return None
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(landed)                      # the last slice has reached the device (side stream)
+            dev_recv.record_stream(cur)
+            return dev_recv
         for r in works:
             r.wait()            # RCCL: orders the current stream behind the transfer (no host block); gloo: host wait
         return recv.to(device) if (stage and recv is not None) else recv
