@@ -83,7 +83,10 @@ struct KOut {
 // Up to MAX_GROUP frames per launch (blockIdx.z = frame): small frames then fill the block slots of the
 // chip without short, halo-heavy blocks, and fewer launches are needed.  The per-frame records travel by
 // value in the kernel-argument segment and are picked with a wave-uniform index (scalar loads).
-constexpr int MAX_GROUP = 8;
+#ifndef CRTFX_MAX_GROUP
+#define CRTFX_MAX_GROUP 8
+#endif
+constexpr int MAX_GROUP = CRTFX_MAX_GROUP;
 struct KGroup { KFrame f[MAX_GROUP]; KOut o[MAX_GROUP]; };
 struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; };
 
