@@ -1,6 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): collects the rocprofv3 evidence bench.py's roofline object refers to.
 # Usage: bash tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>_*   (then tools/summarise_profiles.py <tag> here)
+# After a source change the bench line taken HERE still carries the previous build's traffic.json (nulled as stale): once
+# summarise_profiles.py has written the new one, take `python bench.py > gpurun_out/<tag>_bench.json` again and copy it to profiles/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r02_z}
