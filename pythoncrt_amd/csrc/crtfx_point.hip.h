@@ -15,6 +15,17 @@ namespace crtfx {
 //   * otherwise the generic bilinear taps from the dx/dy axis tables.
 // SF / PIX: gate word and pixel format folded at compile time for a plain render frame (see k_point_lean), or
 // SF = 0xFFFFFFFF for the general build.
+// a1..a4 (+ overlay-before) of the pixel whose SAMPLES sit at the already pixelate-mapped (ys, xs); (y, x): the pixel itself (overlay).
+__device__ __forceinline__ void fetch_graded_mapped(const KParams& P, const KFrame& F, int ys, int xs, int y, int x, float (&v)[3]) {
+    const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
+    int xr = xs, xb = xs;
+    if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }      // ref:573-575
+    const RawRGB raw = load_raw(P.pix, F.in, row + (uint32_t)xr * 3u, row + (uint32_t)xs * 3u + 1u, row + (uint32_t)xb * 3u + 2u);
+    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { v[0] = P.grade_lut[raw.r]; v[1] = P.grade_lut[256 + raw.g]; v[2] = P.grade_lut[512 + raw.b]; }
+    else { v[0] = norm_px(P.pix, raw.r); v[1] = norm_px(P.pix, raw.g); v[2] = norm_px(P.pix, raw.b); grade(P, v[0], v[1], v[2]); }
+    if (F.overlay_before) overlay_blend<float>(F.overlay_before, (uint32_t)y * (uint32_t)P.W + (uint32_t)x, v[0], v[1], v[2]);
+}
+
 template <uint32_t SF, int PIX>
 __device__ __forceinline__ void half_body(const KParams& Pin, const KFrame& Fin, float* __restrict__ ds) {
     KParams P = Pin;
@@ -23,28 +34,40 @@ __device__ __forceinline__ void half_body(const KParams& Pin, const KFrame& Fin,
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= P.hw || j >= P.hh) return;
-    float o[3];
-    if (!P.dx_ofs) {
-        float a[3], b[3], c[3], d[3];
-        fetch_graded(P, F, 2 * j, 2 * i, a[0], a[1], a[2]);
-        fetch_graded(P, F, 2 * j, 2 * i + 1, b[0], b[1], b[2]);
-        fetch_graded(P, F, 2 * j + 1, 2 * i, c[0], c[1], c[2]);
-        fetch_graded(P, F, 2 * j + 1, 2 * i + 1, d[0], d[1], d[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;
+    // the four taps: (x0, y0) (x1, y0) (x0, y1) (x1, y1)
+    int x0, x1, y0, y1;
+    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+    const bool mean4 = !P.dx_ofs;
+    if (mean4) { x0 = 2 * i; x1 = 2 * i + 1; y0 = 2 * j; y1 = 2 * j + 1; }
+    else {
+        x0 = P.dx_ofs[i]; y0 = P.dy_ofs[j];
+        x1 = min(x0 + 1, P.W - 1); y1 = min(y0 + 1, P.H - 1);
+        a1 = P.dx_a[i]; a0 = 1.0f - a1; b1 = P.dy_a[j]; b0 = 1.0f - b1;
+    }
+    float a[3], b[3], c[3], d[3];
+    if (P.flags & CRTFX_F_PIXELATE) {
+        // With pixelate on, neighbouring taps usually read the SAME source pixel (pixel size 2, the reference CLI's default: all
+        // four of a 2x2 mean) — fetch and grade each distinct one once.  Identical inputs, so the sums below are the same bits.
+        const int mx0 = P.xmap[x0], mx1 = P.xmap[x1], my0 = P.ymap[y0], my1 = P.ymap[y1];
+        const bool share = !F.overlay_before;       // (an overlay is blended per output pixel: no sharing then)
+        const bool same_x = share && mx1 == mx0, same_y = share && my1 == my0;
+        fetch_graded_mapped(P, F, my0, mx0, y0, x0, a);
+        if (same_x) { b[0] = a[0]; b[1] = a[1]; b[2] = a[2]; } else fetch_graded_mapped(P, F, my0, mx1, y0, x1, b);
+        if (same_y) { c[0] = a[0]; c[1] = a[1]; c[2] = a[2]; } else fetch_graded_mapped(P, F, my1, mx0, y1, x0, c);
+        if (same_x) { d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
+        else if (same_y) { d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; }
+        else fetch_graded_mapped(P, F, my1, mx1, y1, x1, d);
     } else {
-        const int sx = P.dx_ofs[i], sy = P.dy_ofs[j];
-        const int sx1 = min(sx + 1, P.W - 1), sy1 = min(sy + 1, P.H - 1);
-        const float a1 = P.dx_a[i], a0 = 1.0f - a1, b1 = P.dy_a[j], b0 = 1.0f - b1;
-        float a[3], b[3], c[3], d[3];
-        fetch_graded(P, F, sy, sx, a[0], a[1], a[2]);
-        fetch_graded(P, F, sy, sx1, b[0], b[1], b[2]);
-        fetch_graded(P, F, sy1, sx, c[0], c[1], c[2]);
-        fetch_graded(P, F, sy1, sx1, d[0], d[1], d[2]);
+        fetch_graded(P, F, y0, x0, a[0], a[1], a[2]);
+        fetch_graded(P, F, y0, x1, b[0], b[1], b[2]);
+        fetch_graded(P, F, y1, x0, c[0], c[1], c[2]);
+        fetch_graded(P, F, y1, x1, d[0], d[1], d[2]);
+    }
+    float o[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            o[k] = (bloom_src(P, a[k]) * a0 + bloom_src(P, b[k]) * a1) * b0 + (bloom_src(P, c[k]) * a0 + bloom_src(P, d[k]) * a1) * b1;
+    for (int k = 0; k < 3; ++k) {
+        if (mean4) o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;
+        else o[k] = (bloom_src(P, a[k]) * a0 + bloom_src(P, b[k]) * a1) * b0 + (bloom_src(P, c[k]) * a0 + bloom_src(P, d[k]) * a1) * b1;
     }
     float* q = ds + ((size_t)j * P.hw + i) * 3;
     q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
