@@ -105,7 +105,7 @@ def source_hash():
     import hashlib
     h = hashlib.sha1()
     for f in ("pythoncrt_amd/csrc/crtfx_kernels.hip.h", "pythoncrt_amd/csrc/crtfx_common.hip.h", "pythoncrt_amd/csrc/crtfx_blur.hip.h",
-              "pythoncrt_amd/csrc/crtfx_point.hip.h", "pythoncrt_amd/csrc/crtfx_phosphor.hip.h", "pythoncrt_amd/csrc/crtfx_warp.hip.h",
+              "pythoncrt_amd/csrc/crtfx_point.hip.h", "pythoncrt_amd/csrc/crtfx_phosphor.hip.h", "pythoncrt_amd/csrc/crtfx_phosphor_ct.hip.h", "pythoncrt_amd/csrc/crtfx_warp.hip.h",
               "pythoncrt_amd/csrc/crtfx.hip", "pythoncrt_amd/csrc/crtfx_rr.hip", "pythoncrt_amd/csrc/crtfx_internal.h", "include/crtfx.h"):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
@@ -128,7 +128,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[N-1]; 0 = the reference CLI's default flags at 1080p")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 320 at 4K, 1536 at 1080p, 64 at 8K — sized so that 20 steps run >= 0.5 s)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 1600 at 4K, 7680 at 1080p, 320 at 8K — sized so that the default 20 steps run >= 3 s)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of K steps after the reported one (spread only; 0 = none)")
@@ -196,21 +196,24 @@ def main():
     rs, h, w = baseline_config(a.config)
     fps = 30.0
     p = rs.persistence
-    # frames per step: enough that the default 20 steps run >= 0.5 s (4K: 256 frames = 6.4 GB in + 6.4 GB out of the
-    # 288 GB; the sharded-persistence config needs B >= settle_frames(p) anyway, see shard.py)
-    from pythoncrt_amd.shard import choose_chunk
-    B = a.batch or (64 if h >= 4320 else 320 if h >= 2160 else 1536)
+    # frames per step: enough that the default 20 steps run >= 3 s — a timed region the driver's 5-s GPU-busy sampler
+    # cannot miss (4K: 1600 frames = 39.8 GB in + 39.8 GB out of the 288 GB; 1080p: 7680 frames = 47.8 GB each way; 8K fp16:
+    # 320 frames = 63.7 GB each way).  Sharded persistence needs B >= settle_frames(p) anyway (shard.py); per-frame states
+    # are kept for the first 26 frames of a chunk only (GpuShardEngine.keep), so a long chunk costs output frames, not states.
+    B = a.batch or (320 if h >= 4320 else 1600 if h >= 2160 else 7680)
     if p > 0.0 and not a.batch:
-        # sharded persistence: a chunk covers the IIR's settling time, so every round is ONE parallel hop (shard.py);
-        # 512 frames (2 slots x 512 x 24.9 MB of per-frame states at 1080p) also keeps 20 steps above 0.3 s
-        B = choose_chunk(p, h * w * 12, 512 if world > 1 else 1024)
+        B = max(settle_frames(p), 4096 if world > 1 else 7680)
     dtype = torch.float16 if a.config == 5 else torch.uint8
     pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234, dtype=dtype)
     frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank).to(dtype)
     shard = FrameShard(world, rank, B)
     sharded_iir = p > 0.0 and world > 1
     engine = GpuShardEngine(pipe, B, slots=2 if sharded_iir else 1)
-    render = ShardedRender(shard, p, engine, dist=dist, overlap=sharded_iir, timing=sharded_iir)
+    # the overlapped hop schedule is the default over gloo (rehearsals) only: its RCCL branch has never run on hardware
+    # (no multi-GPU box in this pipeline), and at these chunk sizes the synchronous hop costs < 2 % of a round
+    # (0.16 ms of one xGMI link + 0.17 ms of fix-up against a >= 20 ms scan); CRTFX_SHARD_OVERLAP=1 opts in.
+    want_overlap = sharded_iir and (backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1")
+    render = ShardedRender(shard, p, engine, dist=dist, overlap=want_overlap, timing=sharded_iir)
 
     # step s = round s of the frame-sharded render: rank r owns global frames [(s*world + r)*B, ... + B).
     # The per-frame host tables of a step (scanline row gains via np.sin, flicker factors, the ctypes frame records and
@@ -231,7 +234,7 @@ def main():
     def one_step(s_):
         if not a.tables_outside:
             build_tables(s_)
-        render.submit_round(frames, s_)        # overlapped schedule when the IIR is sharded (results one call late), else run_round
+        render.submit_round(frames, s_)        # overlapped schedule when asked for (results one call late), else run_round
 
     def sync():
         torch.cuda.synchronize(device)
@@ -278,7 +281,12 @@ def main():
     total_frames = B * a.steps * world
     fps_out = total_frames / dt
     px = h * w
-    alg_bytes_frame = px * ((12 if a.config == 5 else 6) + (24 if p > 0 else 0))   # u8 (fp16) in + out (+ f32 state r/w)
+    survey_bytes_frame = px * ((12 if a.config == 5 else 6) + (24 if p > 0 else 0))   # u8 (fp16) in + out (+ f32 state r/w per frame)
+    # ... but the kernels carry the persistence state in registers through a run of up to CRTFX_MAX_GROUP = 8 frames
+    # (DESIGN.md section 3): the float32 state is read once and written once per RUN, so the bytes the chain has to move
+    # per frame are in + out + 24 B/px / 8.  `roofline.frac` is quoted on that figure; the survey's 30 B/px stays beside it.
+    run_len = 8
+    alg_bytes_frame = px * (12 if a.config == 5 else 6) + (px * 24 // run_len if p > 0 else 0)
     res = {
         "metric": "4K frames/sec (whole node) + achieved HBM GB/s as % of MI355X peak" if a.config == 3 else f"{h}p frames/sec (whole node)",
         "value": round(fps_out, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -301,70 +309,106 @@ def main():
         if kt:
             # kt[k] = (mean ms per launch, timed launches, frames they covered): a launch of the dominant kernel
             # covers fpl frames (crtfx_process_batch groups frames per grid), so everything below is quoted PER LAUNCH
-            # of that kernel = per group of fpl frames, with the other kernel's launches over the same frames added.
-            kt = {k: v for k, v in kt.items() if v[1]}
+            # of that kernel = per group of fpl frames, with the chain's other kernels over the same frames added.
+            kt = {k: v for k, v in kt.items() if v[1] and v[2]}
             per_frame_ms = {k: v[0] * v[1] / v[2] for k, v in kt.items()}
             dom = max(per_frame_ms, key=per_frame_ms.get)
             fpl = kt[dom][2] / kt[dom][1]
             group_ms = sum(per_frame_ms.values()) * fpl
+            if p > 0 and "k_warp" in kt:
+                run_len = max(1.0, kt["k_warp"][2] / kt["k_warp"][1])       # frames per persistence run = frames per k_warp launch
+                alg_bytes_frame = px * (12 if a.config == 5 else 6) + int(px * 24 / run_len)
             alg_launch = alg_bytes_frame * fpl
             achieved = alg_launch / (group_ms * 1e-3) / 1e9
-            # PMC traffic: only when profiles/traffic.json was measured on THIS device code and this config
-            traffic = traffic_raw = None
-            tsrc = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            src_now = source_hash()
+
+            def evidence(name):
+                """profiles/<name>.json entry of this config, only when it was measured on THIS device code."""
+                path = os.path.join(ROOT, "profiles", name)
+                if not os.path.exists(path):
+                    return None, None
                 try:
-                    tj = json.load(open(tpath))
-                    ent = tj.get(f"config{a.config}")
-                    if isinstance(ent, dict) and ent.get("source_hash") == source_hash():
-                        traffic = int(ent["bytes_per_frame_corrected"] * fpl)
-                        traffic_raw = int(ent["bytes_per_frame_as_reported"] * fpl)
-                        tsrc = {k: ent.get(k) for k in ("source_hash", "tag", "batch", "correction")}
-                    elif isinstance(ent, dict):
-                        tsrc = {"stale": True, "measured_on": ent.get("source_hash"), "this_build": source_hash()}
+                    ent = json.load(open(path)).get(f"config{a.config}")
                 except Exception:
-                    traffic = None
-            valu = None
-            vpath = os.path.join(ROOT, "profiles", "valu.json")
-            if os.path.exists(vpath):
-                try:
-                    vj = json.load(open(vpath)).get(f"config{a.config}")
-                    if isinstance(vj, dict) and vj.get("source_hash") == source_hash():
-                        wi = vj["valu_wave_insts_per_frame"]
-                        # issue slots of the chip over the chain's kernel time: 1024 SIMDs, one wave-instruction per 2 cycles
-                        # (MI355X_MICROARCH.md: SIMD-32, a wave64 VALU op takes 2 cycles), at the clock the run held
-                        clk = vj.get("clock_ghz", 2.4)
-                        slots = 1024 * (group_ms / fpl * 1e-3) * clk * 1e9 / 2.0
-                        valu = {"wave_insts_per_frame": int(wi), "issue_frac": round(wi / slots, 4), "clock_ghz": clk,
-                                "source": {k: vj.get(k) for k in ("source_hash", "tag")}}
-                except Exception:
-                    valu = None
+                    return None, None
+                if not isinstance(ent, dict):
+                    return None, None
+                if ent.get("source_hash") != src_now:
+                    return None, {"stale": True, "measured_on": ent.get("source_hash"), "this_build": src_now}
+                return ent, {k: ent.get(k) for k in ("source_hash", "tag", "batch", "correction") if k in ent}
+
+            # PMC traffic: FETCH_SIZE + WRITE_SIZE of separate --pmc passes.  These counters sit between L2 and the fabric: they
+            # count Infinity-Cache (MALL) hits as well as HBM accesses (MI355X_MICROARCH.md, HBM / rocprofv3 section), so the rate
+            # below is FABRIC bandwidth — an upper bound on the HBM traffic, which for a <= 224 MB launch group held under the
+            # 256 MB Infinity Cache is probably close to the algorithmic bytes.
+            tent, tsrc = evidence("traffic.json")
+            traffic = int(tent["bytes_per_frame_corrected"] * fpl) if tent else None
+            traffic_raw = int(tent["bytes_per_frame_as_reported"] * fpl) if tent else None
+            # VALU / LDS pipe occupancy of the chain from the SQ counter passes (tools/summarise_profiles.py)
+            vent, vsrc = evidence("valu.json")
+            valu = lds = None
+            bound, bound_ev = "hbm", {"note": "no SQ counter evidence for this build (profiles/valu.json missing or measured on other sources)"}
+            if vent:
+                clk = vent.get("clock_ghz", 2.4)
+                chain_cycles = (group_ms / fpl) * 1e-3 * clk * 1e9              # shader cycles the chain spends per frame
+                wi = vent["valu_wave_insts_per_frame"]
+                cw = vent.get("valu_cost_weighted_cycles_per_frame")
+                valu = {"wave_insts_per_frame": int(wi),
+                        # literal issue fraction: every wave-instruction priced at 2 cycles (SIMD-32)
+                        "issue_frac": round(wi * 2.0 / (1024 * chain_cycles), 4),
+                        # instructions weighted by their measured issue cost (profiles/r02_valu_cost.txt x the static mix of each
+                        # kernel's ISA, tools/isa_cost.py): the fraction of the chain's SIMD time the VALU is busy
+                        "cost_weighted_frac": round(cw / (1024 * chain_cycles), 4) if cw else None,
+                        "avg_cycles_per_inst": vent.get("valu_avg_cycles_per_inst"),
+                        "clock_ghz": clk, "source": vsrc}
+                la = vent.get("lds_idx_active_cycles_per_frame")
+                if la:
+                    lds = {"pipe_frac": round(la / (256 * chain_cycles), 4),        # SQ_LDS_IDX_ACTIVE over 256 CUs x chain cycles
+                           "bank_conflict_share": round(vent.get("lds_bank_conflict_cycles_per_frame", 0) / la, 4),
+                           "dominant_kernel_pipe_frac": vent.get("dominant_lds_pipe_frac"), "source": vsrc}
+                cand = {"valu": (valu or {}).get("cost_weighted_frac") or 0.0, "lds": (lds or {}).get("pipe_frac") or 0.0,
+                        "fabric": (traffic / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else 0.0,
+                        "hbm": achieved / HBM_PEAK_GBS}
+                order = sorted(cand, key=cand.get, reverse=True)
+                bound = order[0] if cand[order[0]] - cand[order[1]] > 0.15 else f"{order[0]}+{order[1]}"
+                bound_ev = {"fractions_of_each_limit": {k: round(v, 4) for k, v in cand.items()},
+                            "rule": "the busiest resource; two named when within 0.15 of each other",
+                            "dominant_kernel_wave_time": vent.get("dominant_wave_time"), "source": vsrc}
+            fabric = round(traffic / (group_ms * 1e-3) / 1e9, 1) if traffic else None
             res["roofline"] = {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # what the counters say limits the chain (evidence beside it); achieved / peak / frac below stay the HBM
+                # figures the metric asks for: ALGORITHMIC bytes over kernel time against 8 TB/s
+                "bound": bound, "bound_evidence": bound_ev,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_as_reported": traffic_raw, "traffic_source": tsrc,
-                "kernel": f"{dom} (+ the other kernel of the chain over the same frames): algorithmic bytes of the frames of one launch / their summed kernel time",
+                "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch group: L2 <-> Infinity Cache / HBM bytes (MALL hits included), not HBM alone",
+                "kernel": f"{dom} (+ the other kernels of the chain over the same frames): algorithmic bytes of the frames of one launch / their summed kernel time",
                 "frames_per_launch": round(fpl, 3), "algorithmic_bytes_per_launch": int(alg_launch),
-                "algorithmic_bytes_per_frame": alg_bytes_frame, "chain_ms_per_launch_group": round(group_ms, 4),
+                "algorithmic_bytes_per_frame": int(alg_bytes_frame),
+                **({"survey_bytes_per_frame": int(survey_bytes_frame),
+                    "persistence_note": "the float32 state is read and written once per run of frames_per_run frames (it stays in registers inside a run), "
+                                        "not once per frame as SURVEY 8d budgets (30 B/px): frac is on the bytes the kernels have to move",
+                    "frames_per_run": round(run_len, 3)} if p > 0 else {}),
+                "chain_ms_per_launch_group": round(group_ms, 4),
                 "dominant_kernel": dom,
                 # the same algorithmic bytes over the dominant kernel's launch duration ALONE (the literal per-kernel reading;
-                # `achieved` above also charges the other kernel of the chain and is the smaller, conservative figure)
+                # `achieved` above also charges the other kernels of the chain and is the smaller, conservative figure)
                 "dominant_kernel_only": {"avg_launch_ms": round(kt[dom][0], 4),
                                          "achieved": round(alg_launch / (kt[dom][0] * 1e-3) / 1e9, 1),
                                          "frac": round(alg_launch / (kt[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                # SURVEY 8d's second figure: fabric bytes the PMC passes counted (FETCH_SIZE + WRITE_SIZE, L2 <-> Infinity
-                # Cache/HBM) over the same kernel time, next to what a plain device copy reaches on this box
-                "hbm_achieved": round(traffic / (group_ms * 1e-3) / 1e9, 1) if traffic else None,
-                "hbm_frac": round(traffic / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                "hbm_frac_as_reported": round(traffic_raw / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_raw else None,
-                "valu": valu,
+                # SURVEY 8d's second figure, named for what the counters see: fabric bytes over the same kernel time, next to what a
+                # plain device copy reaches on this box
+                "fabric_achieved": fabric,
+                "fabric_frac": round(fabric / HBM_PEAK_GBS, 4) if fabric else None,
+                "fabric_frac_as_reported": round(traffic_raw / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_raw else None,
+                "valu": valu, "lds": lds,
                 "copy_ceiling": copy_ceiling(device),
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
             }
         if world == 1 and a.cpu_frames != 0 and a.config != 5:
-            n_cpu = a.cpu_frames if a.cpu_frames > 0 else (12 if h >= 2160 else 40)   # ~10-15 s of CPU work
+            n_cpu = a.cpu_frames if a.cpu_frames > 0 else (8 if h >= 2160 else 32)   # ~10-12 s of CPU work (single thread + the 2-worker repeat)
             v, secs, v2 = cpu_baseline(rs, h, w, fps, n_cpu)
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "frames/s", "cores": 1, "kind": "port",
                                    "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
@@ -374,6 +418,7 @@ def main():
                                                           "note": "the same sample on the reference's 2-thread pool + in-order blend (ref:1015-1017)"}}
         print(json.dumps(res))
     if dist is not None:
+        render.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -222,7 +222,8 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   FORCE_RUNTIME_FLAGS  never take a gate-folded instantiation
  *   NO_CC                full-chain launches that park a pre-warp image stay on k_phosphor_rr (A/B against k_phosphor_cc)
  *   FORCE_CC             ... take k_phosphor_cc for every radius and both pixel formats (it is the default only where it is faster)
- *   GROUP, SEG_ROWS      frames per grid (1..4) / rows per block of the register-window kernels; 0 = the planner's choice
+ *   NO_CT                ... stay on k_phosphor_cc instead of its composite-table build k_phosphor_ct (A/B)
+ *   GROUP, SEG_ROWS      frames per grid (1..8 = CRTFX_MAX_GROUP) / rows per block of the register-window kernels; 0 = the planner's choice
  *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4)
  *   POINT_TILES          rows per k_point block (1..16; 0 = default)
  *   OVERLAP              run k_warp(n) on a side stream beside k_phosphor(n+1) (measured slower; kept for A/B)
@@ -233,7 +234,7 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
 typedef enum crtfx_option {
     CRTFX_OPT_FORCE_GENERIC = 1, CRTFX_OPT_FORCE_RUNTIME_FLAGS = 2, CRTFX_OPT_NO_CC = 3, CRTFX_OPT_GROUP = 4, CRTFX_OPT_SEG_ROWS = 5,
     CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9, CRTFX_OPT_FORCE_CC = 10,
-    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12
+    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12, CRTFX_OPT_NO_CT = 13
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 
@@ -243,7 +244,8 @@ int crtfx_debug_buffer(crtfx_ctx* ctx, void* dev_ptr);
 
 /* HIP-event timing of the launches while profiling is on (events attached to the dispatch packets):
  * on = 0 off, 1 every frame, N > 1 every N-th frame (sampling keeps the overhead negligible).
- * kernel 0 = phosphor (grade+bloom+masks+grain), 1 = warp/commit.  Returns the mean duration of the timed
+ * kernel 0 = phosphor / pointwise chain (grade+bloom+masks+grain), 1 = warp/commit, 2 = the bloom passes launched in
+ * front of a pointwise kernel (k_half / k_half_group, the split bloom's row and column passes).  Returns the mean duration of the timed
  * launches (what `rocprofv3 --kernel-trace --stats` reports as AverageNs), their count, and (frames may be NULL)
  * the number of frames they covered: crtfx_process_batch puts several frames into one grid. */
 int crtfx_profile_enable(crtfx_ctx* ctx, int on);

@@ -4,7 +4,7 @@
 
 See DESIGN.md (path, kernels, roofline) and INTEGRATION.md (how the reference binds to it).
 """
-from .effects import (TriadMask, VignetteMask, apply_crt_effect, apply_static_effects, make_triad_mask,
+from .effects import (DeviceState, TriadMask, VignetteMask, apply_crt_effect, apply_static_effects, make_triad_mask,
                       make_vignette)
 
-__all__ = ["TriadMask", "VignetteMask", "apply_crt_effect", "apply_static_effects", "make_triad_mask", "make_vignette"]
+__all__ = ["DeviceState", "TriadMask", "VignetteMask", "apply_crt_effect", "apply_static_effects", "make_triad_mask", "make_vignette"]

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CRTFX_LIB") or os.path.join(_HERE, "libcrtfx.so")   # CRTFX_LIB: dev A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(CSRC, f) for f in ("crtfx.hip", "crtfx_rr.hip", "crtfx_kernels.hip.h", "crtfx_common.hip.h", "crtfx_blur.hip.h", "crtfx_point.hip.h",
-                                                "crtfx_phosphor.hip.h", "crtfx_warp.hip.h", "crtfx_internal.h")] + \
+                                                "crtfx_phosphor.hip.h", "crtfx_phosphor_ct.hip.h", "crtfx_warp.hip.h", "crtfx_internal.h")] + \
           [os.path.join(ROOT, "include", "crtfx.h")]
 RR_RADII = tuple(range(1, 31))      # one register-window build per radius up to 30 (crtfx_internal.h); larger radii: the split path
 

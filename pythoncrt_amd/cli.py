@@ -229,7 +229,10 @@ def main_sharded(a, rank: int, world: int) -> int:
     shard = FrameShard(world, rank, B)
     # overlapped schedule where the chunk covers the IIR's settling time (shard.py): round r's state frame travels while round
     # r+1 is scanned, results come back one call late; any other case runs the synchronous protocol behind the same calls
-    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=2), dist=dist, overlap=True)
+    # — over gloo (rehearsals).  Over RCCL the synchronous hop stays the default until the overlapped one has run on a multi-GPU
+    # box (it costs ~0.3 ms per round: one state frame over one xGMI link + the fix-up); CRTFX_SHARD_OVERLAP=1 opts in.
+    overlap = backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1"
+    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=2), dist=dist, overlap=overlap)
     if rank == 0:
         with open(a.output, "wb") as f:
             f.truncate(n_frames * frame_bytes)
@@ -258,7 +261,7 @@ def main_sharded(a, rank: int, world: int) -> int:
             frames = host[: hi - lo].to(dev, non_blocking=True)
             uploaded.record()
         commit(render.submit_round(frames, r, active=shard.active_ranks(r, n_frames)))
-    commit(render.flush())
+    commit(render.close())                                # the round still in flight; frees the staged schedule's extra process groups
     os.close(fin); os.close(fout)
     dist.barrier()
     print(f"rank {rank}: {done} of {n_frames} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)

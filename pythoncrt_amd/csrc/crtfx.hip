@@ -40,6 +40,7 @@ struct crtfx_ctx {
     DevBuf triad_row, lut_g, lut_inv, nx2, ny2, xhat, yhat, xmap, ymap, glut, consts;
     DevBuf gxo, gxw, gyo, gyw, uxo, uxw, uyo, uyw, dxo, dxw, dyo, dyw, ds;   // resize axes, half-res scratch (split bloom: two full-res planes)
     DevBuf tpad;                     // split bloom: zero-padded taps (sb_tpad_len)
+    DevBuf tcomp;                    // composite triad tables of k_phosphor_ct: [2][LUT_N]
     bool split = false;              // this parameter set runs the Gaussian bloom as k_sb_src / k_sb_rows / k_sb_cols + the pointwise kernels
     int split_R = 0;                 // its radius (kp.R is 0 then)
     bool split_src_plane = false;    // CRTFX_OPT_SPLIT_SRC_PLANE
@@ -48,7 +49,7 @@ struct crtfx_ctx {
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
     int group_seg = 128;             // rows per block when a full group is launched (plan_grid)
-    int seg_for[3][MAX_GROUP + 1] = {};             // planned rows per block for a (partial) group of g frames, per kernel build (runtime gates / folded / cc)
+    int seg_for[4][MAX_GROUP + 1] = {};             // planned rows per block for a (partial) group of g frames, per kernel build (runtime gates / folded / cc / ct)
     // two-stream overlap of k_warp(n) with k_phosphor(n+1): side stream, per-slot events, 2 scratch slots
     bool overlap = false;
     hipStream_t side = nullptr;
@@ -62,6 +63,7 @@ struct crtfx_ctx {
     bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
     bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
+    bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
     bool debug_plan = false;
     std::string err;
@@ -70,9 +72,9 @@ struct crtfx_ctx {
     int prof_stride = 1;             // time the launches of every prof_stride-th frame
     unsigned prof_frame = 0;         // frames seen since profiling was switched on
     bool prof_this = false;          // the current frame is a sampled one
-    std::vector<hipEvent_t> ev[2];   // pairs (start, stop) per launch, per kernel class
-    std::vector<int> ev_frames[2];   // frames covered by each timed launch
-    size_t ev_used[2] = {0, 0};
+    std::vector<hipEvent_t> ev[3];   // pairs (start, stop) per launch, per kernel class (0 phosphor / point, 1 warp / commit, 2 bloom passes in front of class 0)
+    std::vector<int> ev_frames[3];   // frames covered by each timed launch
+    size_t ev_used[3] = {0, 0, 0};
 };
 
 namespace {
@@ -211,12 +213,12 @@ int pick_seg_rows(int H, int W, int R, int pix = 0, int group = 1) {
 // measured landscape (4K, R = 9: g=1/seg=128 -> 19 it/frame = 89 us; g=2/seg=256 -> 17.5 = 82.5 us, the short
 // last-segment blocks freeing slots for the overflow; g=2/seg=240 -> two full rounds = 103 us).
 struct GridPlan { int g, seg; };
-GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed, bool cc = false) {
+GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed, int cc = 0) {      // cc: 0 = k_phosphor_rr, 1 = k_phosphor_cc, 2 = k_phosphor_ct
     const int strips = (W + TW - 1) / TW;
     const int Rk = rr_build_radius(R) ? R : 9;
-    const size_t lds = cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
+    const size_t lds = cc == 2 ? (size_t)ct_lds_words(Rk) * 4 : cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
     int bpc = (int)(163840 / lds);
-    const int by_regs = cc ? cc_min_waves(Rk) : rr_min_waves(Rk, folded);      // a block = one wave per SIMD
+    const int by_regs = cc == 2 ? ct_min_waves(Rk) : cc ? cc_min_waves(Rk) : rr_min_waves(Rk, folded);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
     const int slots = bpc * 256;
     const int hcap = ((H + NB - 1) / NB) * NB;
@@ -304,14 +306,15 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     // image with 32-bit byte offsets.
     bool cc = folded && !pix_fold && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
-    int& seg_slot = c->seg_for[cc ? 2 : (folded ? 1 : 0)][g];
-    if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, cc).seg;   // planned once per (kernel build, group size)
+    const bool ct = cc && !c->no_ct && c->pix_fmt == CRTFX_PIX_U8;       // the composite-table build of the same kernel (uint8 frames)
+    int& seg_slot = c->seg_for[ct ? 3 : cc ? 2 : (folded ? 1 : 0)][g];
+    if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, ct ? 2 : cc ? 1 : 0).seg;   // planned once per (kernel build, group size)
     const int seg = seg_slot;
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
-    const int variant = cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
+    const int variant = ct ? 6 : cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
     const bool runtime = !folded;
-    const size_t lds = cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
+    const size_t lds = ct ? (size_t)ct_lds_words(R) * 4 : cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
                           : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
     ProfEv pe(c, 0, g);
     table[R](c->kp, kg, seg, dim3(strips, segs, g), lds, s, variant, pe.e0, pe.e1);
@@ -404,20 +407,23 @@ void launch_split_blur(crtfx_ctx* c, const KFrame& kf, hipStream_t s) {
     const unsigned long long* tp = (const unsigned long long*)c->tpad.p;
     const int npairs = sb_tpad_len(R) / 2;
     const dim3 gr((W + SB_SPAN - 1) / SB_SPAN, (H + SB_RW - 1) / SB_RW), br(64 * SB_RW);
+    // timed as kernel class 2 (the bloom passes in front of the pointwise kernel); the first launch carries the frame count
+    ProfEv p0(c, 2, 1), p1(c, 2, 0);
     if (c->split_src_plane) {      // CRTFX_OPT_SPLIT_SRC_PLANE (A/B): the bloom source as its own plane first
         dim3 gs((W + 63) / 64, (H + 3) / 4);
-        if (c->pix_fmt == CRTFX_PIX_F16) hipLaunchKernelGGL((k_sb_src<CRTFX_PIX_F16>), gs, dim3(256), 0, s, c->kp, kf);
-        else hipLaunchKernelGGL((k_sb_src<CRTFX_PIX_U8>), gs, dim3(256), 0, s, c->kp, kf);
-        hipLaunchKernelGGL((k_sb_rows<-1>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
-    } else if (c->pix_fmt == CRTFX_PIX_F16) hipLaunchKernelGGL((k_sb_rows<CRTFX_PIX_F16>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
-    else hipLaunchKernelGGL((k_sb_rows<CRTFX_PIX_U8>), gr, br, 0, s, c->kp, kf, (const float*)A, B, R, tp, npairs);
+        ProfEv ps(c, 2, 0);
+        if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_sb_src<CRTFX_PIX_F16>), gs, dim3(256), 0, s, ps.e0, ps.e1, c->kp, kf); }
+        else { CRTFX_LAUNCH((k_sb_src<CRTFX_PIX_U8>), gs, dim3(256), 0, s, ps.e0, ps.e1, c->kp, kf); }
+        CRTFX_LAUNCH((k_sb_rows<-1>), gr, br, 0, s, p0.e0, p0.e1, c->kp, kf, (const float*)A, B, R, tp, npairs);
+    } else if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_sb_rows<CRTFX_PIX_F16>), gr, br, 0, s, p0.e0, p0.e1, c->kp, kf, (const float*)A, B, R, tp, npairs); }
+    else { CRTFX_LAUNCH((k_sb_rows<CRTFX_PIX_U8>), gr, br, 0, s, p0.e0, p0.e1, c->kp, kf, (const float*)A, B, R, tp, npairs); }
     const int rowlen = 3 * W;
     if ((W & 3) == 0 && !c->split_src_plane) {
         const int nbx = (rowlen + 255) / 256, nby = (H + SBC_W * SB_N - 1) / (SBC_W * SB_N);
-        hipLaunchKernelGGL(k_sb_cols_lds, dim3(8 * ((nbx * nby + 7) / 8)), dim3(64 * SBC_W), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs, nbx, nby);
+        CRTFX_LAUNCH(k_sb_cols_lds, dim3(8 * ((nbx * nby + 7) / 8)), dim3(64 * SBC_W), 0, s, p1.e0, p1.e1, (const float*)B, A, H, rowlen, R, tp, npairs, nbx, nby);
     }
-    else if ((W & 3) == 0) hipLaunchKernelGGL((k_sb_cols<4>), dim3((rowlen + 255) / 256, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs);
-    else hipLaunchKernelGGL((k_sb_cols<1>), dim3((rowlen + 63) / 64, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, (const float*)B, A, H, rowlen, R, tp, npairs);
+    else if ((W & 3) == 0) { CRTFX_LAUNCH((k_sb_cols<4>), dim3((rowlen + 255) / 256, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, p1.e0, p1.e1, (const float*)B, A, H, rowlen, R, tp, npairs); }
+    else { CRTFX_LAUNCH((k_sb_cols<1>), dim3((rowlen + 63) / 64, (H + 4 * SB_N - 1) / (4 * SB_N)), dim3(256), 0, s, p1.e0, p1.e1, (const float*)B, A, H, rowlen, R, tp, npairs); }
 }
 
 // The whole chain for one frame.  ko describes the FINAL outputs.
@@ -459,13 +465,14 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
             const uint32_t g0 = fl & ~(uint32_t)CRTFX_F_WARP;
             const bool fold = !c->force_generic && !c->force_runtime_flags && (g0 == SF_FAST || g0 == SF_FAST_PIX) && !kf.overlay_before;
             const bool f16 = c->pix_fmt == CRTFX_PIX_F16;
-            if (!fold) hipLaunchKernelGGL((k_half<SF_RUNTIME, 0>), gh, dim3(256), 0, s, c->kp, kf);
+            ProfEv ph(c, 2);
+            if (!fold) { CRTFX_LAUNCH((k_half<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
             else if (g0 == SF_FAST_PIX) {
-                if (f16) hipLaunchKernelGGL((k_half<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kf);
-                else hipLaunchKernelGGL((k_half<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kf);
+                if (f16) { CRTFX_LAUNCH((k_half<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
+                else { CRTFX_LAUNCH((k_half<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
             } else {
-                if (f16) hipLaunchKernelGGL((k_half<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kf);
-                else hipLaunchKernelGGL((k_half<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kf);
+                if (f16) { CRTFX_LAUNCH((k_half<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
+                else { CRTFX_LAUNCH((k_half<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
             }
         }
         ProfEv pe(c, 0);
@@ -548,7 +555,7 @@ int crtfx_destroy(crtfx_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&c->consts, &c->glut, &c->triad_row, &c->lut_g, &c->lut_inv, &c->nx2, &c->ny2, &c->xhat, &c->yhat, &c->xmap, &c->ymap, &c->gxo, &c->gxw,
-                      &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds}) free_buf(*b);
+                      &c->gyo, &c->gyw, &c->uxo, &c->uxw, &c->uyo, &c->uyw, &c->dxo, &c->dxw, &c->dyo, &c->dyw, &c->ds, &c->tpad, &c->tcomp}) free_buf(*b);
     if (c->pre) (void)hipFree(c->pre);
     for (auto& v : c->ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) { if (c->ev_k1[i]) (void)hipEventDestroy(c->ev_k1[i]); if (c->ev_k2[i]) (void)hipEventDestroy(c->ev_k2[i]); }
@@ -655,6 +662,46 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
     k.triad_full = p->triad_full_dev;
     k.lut_g = (const float*)c->lut_g.p; k.lut_inv = (const float*)c->lut_inv.p;
     k.grade_lut = use_glut ? (const float*)c->glut.p : nullptr;
+    // k_phosphor_ct: the two LUT steps of the triad mask composed per mask value, T_m[i] = lut_inv[idx(lut_g[i] * m)] (ref:246-263 with
+    // preserve-luma off), for the two most frequent values of the mask row — the float32 product and the truncation are the
+    // kernels' own (tail_masks: lut_g[i] * m, lut_index), so a gather from T_m returns the very float the two gathers would
+    k.triad_comp = nullptr; k.comp_m0 = k.comp_m1 = 0u;
+    if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT) && !(fl & CRTFX_F_TRIAD_LUMA) && p->triad_row && !p->triad_full_dev) {
+        const float* row = p->triad_row;
+        uint32_t vals[2] = {0u, 0u};
+        size_t cnt[2] = {0, 0};
+        {   // the two most frequent bit patterns: a softened period-3 mask has two or three interior values plus a few border ones
+            std::vector<std::pair<uint32_t, size_t>> hist;
+            for (size_t i = 0; i < (size_t)W * 3; ++i) {
+                uint32_t b; std::memcpy(&b, row + i, 4);
+                size_t j = 0;
+                for (; j < hist.size(); ++j) if (hist[j].first == b) { ++hist[j].second; break; }
+                if (j == hist.size()) { if (hist.size() >= 64) break; hist.emplace_back(b, 1); }      // a mask with that many values is not a period-3 row: no composite form
+            }
+            for (auto& h : hist) {
+                if (h.second > cnt[0]) { vals[1] = vals[0]; cnt[1] = cnt[0]; vals[0] = h.first; cnt[0] = h.second; }
+                else if (h.second > cnt[1]) { vals[1] = h.first; cnt[1] = h.second; }
+            }
+            if (cnt[1] == 0) vals[1] = vals[0];
+        }
+        if (cnt[0] > 0) {
+            const float* lg = static_cast<const float*>(p->lut_g);
+            const float* li = static_cast<const float*>(p->lut_inv);
+            std::vector<float> tab(2 * LUT_N);
+            for (int t = 0; t < 2; ++t) {
+                float m; std::memcpy(&m, &vals[t], 4);
+                for (int i = 0; i < LUT_N; ++i) {
+                    volatile float q = lg[i] * m;                       // one float32 rounding, as the kernels' v_mul_f32
+                    float v = q;
+                    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);       // lut_index: (int)(clip01(v) * 1024.0f); a NaN product clips to 0 as fminf(fmaxf()) does
+                    if (!(q == q)) v = 0.0f;
+                    tab[(size_t)t * LUT_N + i] = li[(int)(v * 1024.0f)];
+                }
+            }
+            if ((rc = upload(c, c->tcomp, tab.data(), tab.size() * sizeof(float)))) return rc;
+            k.triad_comp = (const float*)c->tcomp.p; k.comp_m0 = vals[0]; k.comp_m1 = vals[1];
+        }
+    }
     {
         float cst[32 + 256] = {1.0f, 1.0f, 1.0f, 1.0f};      // then zeros: the address a disabled stage loads from in k_point_sel
         for (int i = 0; i < 256; ++i) cst[32 + i] = (float)i / 255.0f;      // u / 255 (the IEEE quotient, = norm_u8)
@@ -689,8 +736,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         const bool folded_plan = (gates_plan == SF_FULL || pix_fold_plan) && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
         const bool cc_plan = folded_plan && !pix_fold_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
-        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_plan);
-        if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, c->opt_group, c->opt_group, cc_plan);      // the planner's rows per block for the group size asked for
+        const int cc_build = cc_plan ? ((!c->no_ct && c->pix_fmt == CRTFX_PIX_U8) ? 2 : 1) : 0;
+        GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_build);
+        if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, c->opt_group, c->opt_group, cc_build);      // the planner's rows per block for the group size asked for
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;
         const int need = c->overlap ? 2 * gp.g : gp.g;
         if (need > c->pre_frames) {
@@ -701,9 +749,9 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         }
         c->group_max = gp.g;
         c->group_seg = gp.seg;
-        if (c->debug_plan) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block%s\n", W, H, R, gp.g, gp.seg, cc_plan ? " (k_phosphor_cc)" : "");
-        for (int b = 0; b < 3; ++b) for (int g = 1; g <= MAX_GROUP; ++g) c->seg_for[b][g] = 0;
-        c->seg_for[cc_plan ? 2 : (folded_plan ? 1 : 0)][gp.g] = gp.seg;
+        if (c->debug_plan) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block%s\n", W, H, R, gp.g, gp.seg, cc_build == 2 ? " (k_phosphor_ct)" : cc_build ? " (k_phosphor_cc)" : "");
+        for (int b = 0; b < 4; ++b) for (int g = 1; g <= MAX_GROUP; ++g) c->seg_for[b][g] = 0;
+        c->seg_for[cc_build == 2 ? 3 : cc_build ? 2 : (folded_plan ? 1 : 0)][gp.g] = gp.seg;
     }
 
     if ((fl & CRTFX_F_BLOOM) && R <= GENERIC_MAX_RADIUS) {
@@ -850,9 +898,6 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 KOut k1{};
                 if (two) {
                     k1.pre = c->pre + ((size_t)slot * c->group_max + g) * frame_elems; k1.pix = c->pix_fmt;
-#ifdef CC_EXP_FUSEWARP
-                    k1.out_u8 = final_out(i + g).out_u8;      // timing experiment: the phosphor kernel also writes (wrong) frames
-#endif
                 } else k1 = final_out(i + g);
                 k1.dbg = c->dbg;
                 if (!lean_ok(c, kf, k1)) break;
@@ -867,11 +912,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (ovl && c->ev_k2_pending[slot]) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[slot], 0));   // slot free again
                 launch_rr_group(c, kg, g, s);
                 if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k1[slot], s)); HIP_TRY(c, hipStreamWaitEvent(sw, c->ev_k1[slot], 0)); }
-#ifdef CC_EXP_FUSEWARP
-                if (false) {
-#else
                 if (two) {
-#endif
                     const float* pre0 = c->pre + (size_t)slot * c->group_max * frame_elems;
                     if (!blend_on) {
                         KWarpGroup wg{};
@@ -933,9 +974,10 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 const bool pixelate = gates == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
                 if (fastb) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
-                    if (!lean) hipLaunchKernelGGL((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, c->kp, kg);
-                    else if (pixelate) { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
-                    else { if (f16) hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, c->kp, kg); else hipLaunchKernelGGL((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, c->kp, kg); }
+                    ProfEv ph(c, 2, g);
+                    if (!lean) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
+                    else if (pixelate) { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
+                    else { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                 }
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 ProfEv pe(c, 0, g);
@@ -1053,6 +1095,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_FORCE_GENERIC: c->force_generic = value != 0; break;
     case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
+    case CRTFX_OPT_NO_CT: c->no_ct = value != 0; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
     case CRTFX_OPT_SPLIT_SRC_PLANE: c->split_src_plane = value != 0; break;
     case CRTFX_OPT_SPLIT_FROM: if (value < 0) return fail(c, CRTFX_E_INVALID, "split_from %d < 0", value); c->split_from = value; break;
@@ -1094,12 +1137,12 @@ int crtfx_profile_enable(crtfx_ctx* c, int on) {
     c->prof_stride = on > 1 ? on : 1;      // on = N > 1: sample every N-th frame (a timed dispatch costs ~8 % when every launch is timed)
     c->prof_frame = 0;
     c->prof_this = c->prof;
-    c->ev_used[0] = c->ev_used[1] = 0;
+    c->ev_used[0] = c->ev_used[1] = c->ev_used[2] = 0;
     return CRTFX_OK;
 }
 
 int crtfx_profile_read(crtfx_ctx* c, int kernel, double* mean_launch_ms, int* launches, int* frames) {
-    if (!c || kernel < 0 || kernel > 1 || !mean_launch_ms || !launches) return CRTFX_E_INVALID;
+    if (!c || kernel < 0 || kernel > 2 || !mean_launch_ms || !launches) return CRTFX_E_INVALID;
     const size_t u = c->ev_used[kernel];
     double total = 0.0;
     int cnt = 0, fr = 0;

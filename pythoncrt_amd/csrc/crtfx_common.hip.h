@@ -35,6 +35,8 @@ struct KParams {
     const float* __restrict__ lut_g;
     const float* __restrict__ lut_inv;
     const float* __restrict__ grade_lut;   // [3][256]: a1 + a4 per channel and uint8 code (saturation off), or nullptr
+    const float* __restrict__ triad_comp;  // [2][LUT_N]: T_m[i] = lut_inv[idx(lut_g[i] * m)] for the mask values comp_m0 / comp_m1 (k_phosphor_ct), or nullptr
+    uint32_t comp_m0, comp_m1;             // bit patterns of the two tabulated mask values (the most frequent ones of the triad row)
     const double* __restrict__ vig_nx2;
     const double* __restrict__ vig_ny2;
     const double* __restrict__ vig_full;

@@ -17,11 +17,12 @@
 
 //
 // Parts: crtfx_common.hip.h (parameter blocks, per-pixel stages), crtfx_blur.hip.h (split bloom), crtfx_point.hip.h (pointwise chain),
-// crtfx_phosphor.hip.h (fused bloom chain), crtfx_warp.hip.h (warp + utility kernels).  Kernels only the main translation unit
+// crtfx_phosphor.hip.h + crtfx_phosphor_ct.hip.h (fused bloom chain), crtfx_warp.hip.h (warp + utility kernels).  Kernels only the main translation unit
 // needs sit behind CRTFX_MAIN_TU; crtfx_rr.hip (one TU per radius) sees k_phosphor_rr / k_phosphor_cc and their helpers.
 #pragma once
 #include "crtfx_common.hip.h"
 #include "crtfx_blur.hip.h"
 #include "crtfx_point.hip.h"
 #include "crtfx_phosphor.hip.h"
+#include "crtfx_phosphor_ct.hip.h"
 #include "crtfx_warp.hip.h"

@@ -622,36 +622,8 @@ __host__ __device__ constexpr int cc_sws(int R) { return ((rr_swp(R) + 3) & ~7) 
 constexpr int CC_HROW = 3 * TW + 4;       // H-row tile row stride in floats: == 4 (mod 32), the H pass's column-strided stores stay 2-way
 __host__ __device__ constexpr int cc_cring_words(int R, int pix) { return pix ? (rr_cring(R) * TW * 3 + 1) / 2 : rr_cring(R) * TW; }   // half: [CR][TW][3] uint16; uint8: [CR][TW] packed r | g<<8 | b<<16
 // LDS words: staging, ONE H-row tile, LUTs, centre ring, a1 table (uint8), vignette tile (f64), two grain tiles (f32), row table
-#ifdef CC_EXP_FUSEWARP
-// TIMING EXPERIMENT, never shipped ("Fusing the warp"): the tail's pixels go to a 16-row LDS ring instead of
-// HBM and every consumer thread also does k_warp_lean's work for its share of the block's 8 x 64 output pixels — map
-// coordinates, four 12-byte taps (from the ring, at pseudo-addresses: the pixels are WRONG, the instruction stream, LDS
-// traffic and stores are those of a fused kernel without its ownership search and halo), float64 interpolation, quantise,
-// uint8 row store.  A lower bound on what a real fused kernel would cost.
-constexpr int CC_WRING_WORDS = 2 * NB * 3 * TW;
-struct WarpTapsE { F3 A, B, C, D; float u00, u01, u10, u11; };
-__device__ __forceinline__ void warp_coords_e(const KParams& P, int y, int x, int& ix, int& iy, int& fx, int& fy) {      // = warp_coords
-    const float xv = P.xhat[x], yv = P.yhat[y];
-    const float r2 = xv * xv + yv * yv;
-    const float factor = 1.0f + P.warp_k * r2;
-    const float mx = (xv * factor) * P.cx + P.cx;
-    const float my = (yv * factor) * P.cy + P.cy;
-    const int sx = (int)rintf(mx * 32.0f);
-    const int sy = (int)rintf(my * 32.0f);
-    ix = min(max(sx >> 5, -32768), 32767);
-    iy = min(max(sy >> 5, -32768), 32767);
-    fx = sx & 31; fy = sy & 31;
-}
-__device__ __forceinline__ void warp_combine_e(const WarpTapsE& t, double& o0, double& o1, double& o2) {                   // = warp_combine<double>
-    o0 = (((double)t.A.x * (double)t.u00 + (double)t.B.x * (double)t.u01) + (double)t.C.x * (double)t.u10) + (double)t.D.x * (double)t.u11;
-    o1 = (((double)t.A.y * (double)t.u00 + (double)t.B.y * (double)t.u01) + (double)t.C.y * (double)t.u10) + (double)t.D.y * (double)t.u11;
-    o2 = (((double)t.A.z * (double)t.u00 + (double)t.B.z * (double)t.u01) + (double)t.C.z * (double)t.u10) + (double)t.D.z * (double)t.u11;
-}
-#else
-constexpr int CC_WRING_WORDS = 0;
-#endif
 __host__ __device__ constexpr int cc_lds_words(int R, int pix) {
-    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + cc_cring_words(R, pix) + (pix ? 0 : 256) + NB * TW * 2 + 2 * NB * TW + 16 * 4 + CC_WRING_WORDS;
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + cc_cring_words(R, pix) + (pix ? 0 : 256) + NB * TW * 2 + 2 * NB * TW + 16 * 4;
 }
 __host__ __device__ constexpr int cc_min_waves(int R) { return R <= 12 ? 4 : (R <= 20 ? 3 : 2); }
 #ifndef CC_A3
@@ -688,9 +660,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     constexpr uint32_t GVIG_B = NLUT_B + (PIX == 0 ? 256 * 4 : 0);           // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
     constexpr uint32_t ROWTAB_B = GN_B + 2 * NB * TW * 4;                    // [16][4] uint32          scan gain bits, ny2 lo, ny2 hi, -
-    constexpr uint32_t WRING_B = ROWTAB_B + 16 * 4 * 4;                      // CC_EXP_FUSEWARP only: [2][NB][TW][3] float
-    static_assert(WRING_B + CC_WRING_WORDS * 4 == (uint32_t)cc_lds_words(R, PIX) * 4, "LDS map and cc_lds_words disagree");
-    (void)WRING_B;
+    static_assert(ROWTAB_B + 16 * 4 * 4 == (uint32_t)cc_lds_words(R, PIX) * 4, "LDS map and cc_lds_words disagree");
     float* stg = smem;
     float* hrow = smem + HROW_B / 4;
     float* lut = smem + LUT_B / 4;
@@ -863,37 +833,6 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
         for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
                                         c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
             // ---- phase 1 ----
-#ifdef CC_EXP_FUSEWARP
-            {
-                const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, (int)((uint32_t)H * (uint32_t)W * 3u), 0x00020000);
-                const int yb2 = hb - 2 * NB - R;                     // rows the previous trip's C2 left in the ring
-                const int xw = min(x0 + lane, W - 1);
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int jj = 3 * u + wave;                     // this wave's output row of the block (8 of the 9 slots exist)
-                    if (jj < NB) {
-                        const int yy = yb2 + jj;
-                        const int yc = min(max(yy, 0), H - 1);
-                        int ix, iy, fx, fy;
-                        warp_coords_e(P, yc, xw, ix, iy, fx, fy);
-                        WarpTapsE t;
-                        const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
-                        const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
-                        const float mx0 = (unsigned)ix < (unsigned)W ? wx0 : 0.0f, mx1 = (unsigned)(ix + 1) < (unsigned)W ? wx1 : 0.0f;
-                        t.u00 = wy0 * mx0; t.u01 = wy0 * mx1; t.u10 = wy1 * mx0; t.u11 = wy1 * mx1;
-                        const uint32_t ra = (uint32_t)(iy & 15) * (3 * TW * 4), rb = (uint32_t)((iy + 1) & 15) * (3 * TW * 4);
-                        const uint32_t ca = (uint32_t)(ix & 63) * 12u, cb = (uint32_t)((ix + 1) & 63) * 12u;
-                        auto px = [&](uint32_t o) { return F3{LDS_AT(lds_f32_t, WRING_B + o), LDS_AT(lds_f32_t, WRING_B + o + 4), LDS_AT(lds_f32_t, WRING_B + o + 8)}; };
-                        t.A = px(ra + ca); t.B = px(ra + cb); t.C = px(rb + ca); t.D = px(rb + cb);
-                        double w0, w1, w2;
-                        warp_combine_e(t, w0, w1, w2);
-                        const bool rowok = yy >= y_begin && yy < y_end;     // wave-uniform
-                        store_row_u8_buf(out_rs, rowok ? ((uint32_t)yc * (uint32_t)W + (uint32_t)x0) * 3u : 0xFFFFFF00u, lane, min(64, W - x0),
-                                         quant_u8x3((float)w0, (float)w1, (float)w2), (W & 3) == 0);
-                    }
-                }
-            }
-#endif
             float v[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {              // centre sample of output row hb - NB - R + j (a1; a2 is in the parked sample); garbage in trip 0
@@ -904,21 +843,14 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 else v[j] = norm_u8((uint32_t)LDS_AT(lds_u8_t, CRING_B + (uint32_t)(cr * TW * 4) + cpl));
             }
             float blur[NB];
-#ifdef CC_EXP_ANLUT_TA      // A/B: the A items' a1 lookups as L1 gathers from a global copy of the table, issued before the V pass
-            float nv[AO][3];
-#pragma unroll
-            for (int u = 0; u < AO; ++u) { nv[u][0] = P.consts[32 + raw[u].r]; nv[u][1] = P.consts[32 + raw[u].g]; nv[u][2] = P.consts[32 + raw[u].b]; }
-#endif
             CC_PRIO(CC_P_VH);
             v_pass(blur);
             CC_PRIO(CC_P_A);
             STAMP(4);
             {
-#ifndef CC_EXP_ANLUT_TA
                 float nv[AO][3];
 #pragma unroll
                 for (int u = 0; u < AO; ++u) a_lookup(raw[u], nv[u]);
-#endif
 #pragma unroll
                 for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u], nv[u]);
             }
@@ -960,12 +892,7 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
                 for (int j = 0; j < NB; ++j) {
                     const int y = yb + j;
                     const uint32_t oob = (y >= y_begin && y < y_end) ? 0u : 0xFFFFFFFFu;       // wave-uniform
-#ifdef CC_EXP_FUSEWARP
-                    LDS_AT(lds_f32_t, WRING_B + (uint32_t)((((n & 1) * NB + j) * 3 * TW + f) * 4)) = v[j];
-                    (void)oob;
-#else
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff | oob, 0, 0);
-#endif
                     boff += row_b;
                 }
             }

@@ -147,6 +147,76 @@ def _recognise_vignette(mask):
     return hit if hit else mask
 
 
+class DeviceState:
+    """The float image `apply_crt_effect` returns for a numpy frame (its second result, ref:699): an array-like that OWNS
+    the device tensor and materialises a numpy array only when one is asked for (`np.asarray`, indexing, arithmetic, any
+    ndarray attribute).  The reference's GUI tick only threads the value back in —
+    `out, self.prev_img = apply_crt_effect(..., state_prev=self.prev_img)` (ref:1810-1852) — and handed back as
+    `state_prev` it is used where it lies: no 25 MB download and upload per 1080p tick.  `np.asarray(state)` is the
+    float32 array the call returned before."""
+
+    __array_priority__ = 100.0
+
+    def __init__(self, tensor: torch.Tensor):
+        self._t = tensor
+        self._host = None
+        self._dirty = False                     # the host copy was written to: it is the truth until uploaded again
+        self.shape = tuple(tensor.shape)
+        self.dtype = np.dtype(np.float32)
+        self.ndim = tensor.ndim
+        self.size = int(tensor.numel())
+
+    @property
+    def tensor(self) -> torch.Tensor:
+        """The device tensor (float32 H x W x 3); re-uploaded first if the host copy was modified through this object."""
+        if self._dirty:
+            self._t = torch.from_numpy(np.ascontiguousarray(self._host)).to(self._t.device)
+            self._dirty = False
+        return self._t
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self._t.cpu().numpy()
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __setitem__(self, k, v):
+        self.numpy()[k] = v
+        self._dirty = True
+
+    def __getattr__(self, name):                # anything else an ndarray has (astype, mean, min, T, tobytes, ...)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+    def __repr__(self):
+        return f"DeviceState(shape={self.shape}, float32, device={self._t.device}, {'materialised' if self._host is not None else 'device-resident'})"
+
+
+def _state_op(name):
+    def op(self, *args):
+        return getattr(self.numpy(), name)(*[a.numpy() if isinstance(a, DeviceState) else a for a in args])
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "mod", "radd", "rsub", "rmul", "rtruediv", "rfloordiv", "rpow", "rmod",
+           "neg", "pos", "abs", "lt", "le", "gt", "ge", "eq", "ne", "matmul", "rmatmul"):
+    setattr(DeviceState, f"__{_n}__", _state_op(f"__{_n}__"))
+DeviceState.__hash__ = None
+
+
 def make_triad_mask(h: int, w: int, strength: float, softness_px: float = 0.0) -> TriadMask:
     """ref:220-235."""
     return TriadMask(h, w, strength, softness_px, tables.triad_row(_lib.load(), int(w), strength, softness_px))
@@ -177,7 +247,7 @@ def _fresh_seed() -> int:
 # {"FORCE_GENERIC": 1}.  Empty in the product path; nothing reads the environment.
 DEBUG_OPTIONS = {}
 _OPTION_IDS = {"FORCE_GENERIC": 1, "FORCE_RUNTIME_FLAGS": 2, "NO_CC": 3, "GROUP": 4, "SEG_ROWS": 5, "WARP_ROWS": 6, "POINT_TILES": 7,
-               "OVERLAP": 8, "DEBUG_PLAN": 9, "FORCE_CC": 10, "SPLIT_FROM": 11, "SPLIT_SRC_PLANE": 12}
+               "OVERLAP": 8, "DEBUG_PLAN": 9, "FORCE_CC": 10, "SPLIT_FROM": 11, "SPLIT_SRC_PLANE": 12, "NO_CT": 13}
 
 
 class Engine:
@@ -387,6 +457,8 @@ def _check_shape(got, want, name):
 
 
 def _as_device_tensor(a, device, dtype, shape, name) -> torch.Tensor:
+    if isinstance(a, DeviceState):              # a state this module returned: already on the device
+        a = a.tensor
     if isinstance(a, torch.Tensor):
         t = a.to(device=device, dtype=dtype).contiguous()
     else:
@@ -500,7 +572,8 @@ def apply_crt_effect(
     noise_plane=None,
 ) -> Tuple[object, object]:
     """ref:531-699 — full chain, preview-path persistence (cv2.addWeighted, ref:693) and
-    quantise.  Returns (out_u8, img_float); img_float is the next call's `state_prev`."""
+    quantise.  Returns (out_u8, img_float); img_float is the next call's `state_prev`.  For a numpy frame img_float is
+    a `DeviceState`: float32 H x W x 3 to numpy (`np.asarray`, indexing, arithmetic), resident on the device until asked."""
     fr, was_numpy = _frame_to_device(frame)
     h, w = fr.shape[0], fr.shape[1]
     eng = _engine(fr.device, h, w, _lib.PIX_F16 if fr.dtype == torch.float16 else _lib.PIX_U8)
@@ -537,7 +610,9 @@ def apply_crt_effect(
     # `hold` (per-frame tables) may be released here: the work above is enqueued on torch's current
     # stream and torch's caching allocator only reuses a freed block for later work on that stream.
     if was_numpy:
-        return out.cpu().numpy(), state.cpu().numpy()
+        # the frame goes back as a numpy array (ref:1853 wraps it in a QImage); the float state stays on the device behind
+        # an array-like that materialises on demand and is taken back as `state_prev` without a copy (DeviceState)
+        return out.cpu().numpy(), DeviceState(state)
     return out, state
 
 

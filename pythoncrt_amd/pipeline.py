@@ -121,7 +121,6 @@ class FramePipeline:
         self.engine.set_params(self.static)
         self.lib = self.engine.lib
         self._scan_cache = {}
-        self._hold_scan = None
 
     # ---- per-frame records for frames [first, first+n) -------------------------------------
     def frame_records(self, first: int, n: int, noise_planes: Optional[torch.Tensor] = None):
@@ -135,8 +134,9 @@ class FramePipeline:
         if st.scanline_strength > 0.0:
             phases = t_sec * rs.scanline_speed_px_s                                                 # ref:1043
             if st.scanline_angle == 0.0 and st.scanline_thickness == 1.0:
-                base, offs = self._scan_rows(phases)
-                recs["scan_row_dev"] = base + offs * 4
+                table, offs = self._scan_rows(phases)
+                hold.append(table)                      # the records point into it: it lives as long as they do
+                recs["scan_row_dev"] = table.data_ptr() + offs * 4
             else:
                 # slanted / shaped scanlines: the reference rebuilds an H x W float64 sin/pow mask per frame on the CPU
                 # (ref:308-328); here one small kernel per frame writes it on the device (crtfx_scanline_plane)
@@ -181,7 +181,7 @@ class FramePipeline:
         return recs, hold
 
     def _scan_rows(self, phases: np.ndarray):
-        """Device address of the scanline row gains of every frame of a batch: (base pointer, float offset per frame).
+        """The scanline row gains of every frame of a batch: (device table, float offset per frame into it).
         The reference evaluates sin on float32(y) + float32(phase) (ref:213-217).  When every phase of the batch is an
         integer (scanline_speed a multiple of fps: the CLI default 30 / 30) those sums are the integers y + phase
         exactly, so ONE table g[k], k = min phase .. max phase + H - 1, holds every row of every frame — frame b's rows
@@ -202,11 +202,9 @@ class FramePipeline:
                 g = tables.scanline_rows_at(k, st.scanline_strength, st.scanline_period_px)      # scanline_rows' expression on the sums themselves
                 hit = (lo, top, torch.from_numpy(g).pin_memory().to(self.device, non_blocking=True))
                 self._scan_cache["table"] = hit
-            self._hold_scan = hit[2]
-            return hit[2].data_ptr(), (ph32.astype(np.int64) - hit[0]).astype(np.uint64)
+            return hit[2], (ph32.astype(np.int64) - hit[0]).astype(np.uint64)
         rows = torch.from_numpy(tables.scanline_rows(self.h, st.scanline_strength, st.scanline_period_px, phases)).to(self.device)
-        self._hold_scan = rows
-        return rows.data_ptr(), np.arange(len(phases), dtype=np.uint64) * np.uint64(self.h)
+        return rows, np.arange(len(phases), dtype=np.uint64) * np.uint64(self.h)
 
     def run(self, frames: torch.Tensor, first_index: int = 0, state: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, noise_planes: Optional[torch.Tensor] = None,
@@ -233,7 +231,7 @@ class FramePipeline:
                 local_states.data_ptr() if local_states is not None else None,
                 torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.lib, self.engine.ctx, rc)
-        self._hold = (hold, self._hold_scan)      # keep per-frame tables alive until the next run replaces them
+        self._hold = hold                         # keep per-frame tables (scanline gains included) alive until the next run replaces them
         return out, (state if p > 0.0 else None)
 
     # ---- profiling hooks (HIP events recorded by the library on the launch stream) ----------
@@ -243,7 +241,7 @@ class FramePipeline:
 
     def profile_read(self):
         out = {}
-        for k, name in ((0, "k_phosphor"), (1, "k_warp")):
+        for k, name in ((0, "k_phosphor"), (1, "k_warp"), (2, "k_bloom_pass")):
             ms, cnt, fr = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
             _lib.check(self.lib, self.engine.ctx,
                        self.lib.crtfx_profile_read(self.engine.ctx, k, ctypes.byref(ms), ctypes.byref(cnt), ctypes.byref(fr)))

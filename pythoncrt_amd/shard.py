@@ -97,7 +97,9 @@ class ShardedRender:
 
     overlap=True (parallel-hop rounds only): `submit_round` enqueues round r's local scan and starts its hop, then
     finishes round r-1 (waits for ITS hop — long done — and runs its fix-up), so the state frame travels while the
-    next round's scan runs; results come back one call late, `flush()` returns the last."""
+    next round's scan runs; results come back one call late, `flush()` returns the last.  The overlapped schedule has
+    run over gloo only (CPU tests at world 2 / 3 / 8, several ranks on one GPU); callers keep the synchronous run_round
+    as the default over RCCL until it has run on a multi-GPU box (bench.py, cli.main_sharded: CRTFX_SHARD_OVERLAP=1 opts in)."""
 
     def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None, overlap: bool = False, timing: bool = False):
         self.shard, self.p, self.engine, self.dist, self.group = shard, float(persistence), engine, dist, group
@@ -115,7 +117,27 @@ class ShardedRender:
                 self._channels.append(dist.new_group(backend="gloo"))      # collective: every rank constructs its ShardedRender
         self._last_transport_s = None
         self._pending = None          # overlapped mode: the round whose hop is in flight
-        self._marks = []              # timing: per finished round (scan events, hop-wait events + host seconds, fix-up events)
+        self._marks = []              # timing: per finished round (scan events, hop-wait events + host seconds, fix-up events); the last MARKS_KEPT rounds
+
+    MARKS_KEPT = 256
+
+    def _mark(self, m):
+        self._marks.append(m)
+        if len(self._marks) > self.MARKS_KEPT:
+            del self._marks[:len(self._marks) - self.MARKS_KEPT]
+
+    def close(self):
+        """Finish the round in flight, stop the staging worker and destroy the extra gloo groups of a staged overlapped
+        schedule (collective: every rank calls it, like the constructor).  Returns what flush() returns."""
+        done = self.flush()
+        if self._worker is not None:
+            self._jobs.put(None)
+            self._worker.join(timeout=30)
+            self._worker = None
+        for g in self._channels:
+            self.dist.destroy_process_group(g)
+        self._channels = []
+        return done
 
     # ---- point-to-point plumbing --------------------------------------------------------------------------------
     def _staged(self, like: torch.Tensor) -> bool:
@@ -313,7 +335,7 @@ class ShardedRender:
         if not self._staged(final_local):
             # RCCL: the transfer is enqueued behind the scan now and runs beside whatever the compute stream does next
             rec["posted"] = self._post(final_local if dst is not None else None, final_local, src, dst)
-        elif final_local.is_cuda:
+        else:                               # gloo + device tensors: staged through pinned host memory on a worker thread
             rec["posted"] = self._post_staged_async(final_local if dst is not None else None, final_local, src, dst)
         prev, self._pending = self._pending, rec
         if prev is not None:
@@ -327,8 +349,6 @@ class ShardedRender:
         h0 = self._ev(final_local)
         import time as _time
         t0 = _time.perf_counter()
-        if rec["posted"] is None:      # gloo staging: posted here, AFTER the next round's scan was enqueued
-            rec["posted"] = self._post(final_local if rec["dst"] is not None else None, final_local, rec["src"], rec["dst"])
         got = self._complete(*rec["posted"], final_local.device)
         host_s = _time.perf_counter() - t0
         h1 = self._ev(final_local)
@@ -347,8 +367,8 @@ class ShardedRender:
             self.engine.correct(rec["local"][:k], carry, p, rec["out"][:k])
             f1 = self._ev(final_local)
         if self.timing:
-            self._marks.append({"scan": rec["scan"], "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s,
-                                "transport_s": self._last_transport_s})
+            self._mark({"scan": rec["scan"], "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s,
+                        "transport_s": self._last_transport_s})
         return rec["round"], rec["out"]
 
     def flush(self):
@@ -438,5 +458,5 @@ class ShardedRender:
             self.engine.correct(local[:k], carry, p, out[:k])
             f1 = self._ev(final_local)
         if self.timing:
-            self._marks.append({"scan": (e0, e1), "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s})
+            self._mark({"scan": (e0, e1), "hop": (h0, h1), "fix": (f0, f1), "hop_host_s": host_s})
         return out

@@ -1,0 +1,103 @@
+"""Full-size oracle parity for the BASELINE configs that round 2 only met at reduced sizes, and the render loop with
+its per-frame records built ahead of the launches.
+
+  * configs[3]: 1080p, full chain, persistence 0.5 — eight frames through crtfx_process_batch, so that the planner's
+    multi-frame k_phosphor group and the in-register persistence chain of k_warp_lean run at the size they are planned
+    for, against the oracle's in-order render (crt_filter.py ref:1086-1098).
+  * configs[4]: one 8K frame held as float16 — the 688-row / multi-round launch shape of the register-window kernel's
+    half build, block seams and all — against the oracle.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import crt_oracle as orc  # noqa: E402  (checker only)
+from tests.test_parity_gpu import _export_planes, make_frame  # noqa: E402
+
+PARAM_KEYS = ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+              "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def test_1080p_persistence_render_loop_against_oracle(dev):
+    """BASELINE configs[3] at full size on one GPU: 8 frames = one full planner group + a partial one; frame 0 passes
+    through unblended (ref:1094-1095), frames 1.. blend in order.  <= 1 LSB, < 0.1 % of the samples, as the 4K test."""
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs, h, w = baseline_config(4)
+    assert (h, w) == (1080, 1920) and rs.persistence == 0.5
+    n, first, seed = 8, 11, 31337
+    frames = np.stack([make_frame(h, w, seed=500 + i, kind="grad" if i % 2 else "noise") for i in range(n)])
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    planes = _export_planes(pipe, seed, first, n, h, w)
+    params = {k: getattr(rs, k) for k in PARAM_KEYS}
+    exp, exp_state = orc.process_frames(list(frames), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
+                                        rs.triad_softness, rs.vignette_strength, noise_planes=planes, first_index=first)
+    got = out.cpu().numpy()
+    for i in range(n):
+        d = np.abs(got[i].astype(np.int16) - exp[i].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (i, int(d.max()), float((d != 0).mean()))
+    assert np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6
+    # the same clip in two calls (a chunk boundary carries the state through HBM instead of registers): identical frames
+    a, st = pipe.run(torch.from_numpy(frames[:3]).to(dev), first_index=first)
+    b, _ = pipe.run(torch.from_numpy(frames[3:]).to(dev), first_index=first + 3, state=st)
+    assert torch.equal(torch.cat([a, b]), out)
+
+
+def test_8k_fp16_frame_against_oracle(dev):
+    """BASELINE configs[4]: one 7680 x 4320 frame of float16 pixels through the render loop against the oracle (about a
+    minute of CPU).  The half output is |x * 255| narrowed (convertScaleAbs without the integer rounding)."""
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs, h, w = baseline_config(5)
+    assert (h, w) == (4320, 7680)
+    first, seed = 2, 808
+    rng = np.random.default_rng(77)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    grad = np.stack([xx * (255.0 / w), yy * (255.0 / h), (xx + yy) * (255.0 / (h + w))], axis=2)
+    frame = ((grad + rng.random((h, w, 3), dtype=np.float32) * 255.0) * 0.5).astype(np.float16)      # fractional values on the 0..255 scale
+    del grad, yy, xx
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed, dtype=torch.float16)
+    out, _ = pipe.run(torch.from_numpy(frame[None]).to(dev), first_index=first)
+    got = out[0].cpu().numpy()
+    planes = _export_planes(pipe, seed, first, 1, h, w)
+    params = {k: getattr(rs, k) for k in PARAM_KEYS}
+    _, st = orc.process_frames([frame], params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                               rs.vignette_strength, noise_planes=planes, first_index=first)
+    exp16 = np.abs(st.astype(np.float32) * np.float32(255.0)).astype(np.float16)
+    assert got.dtype == np.float16 and got.shape == exp16.shape
+    diff = np.abs(got.astype(np.float32) - exp16.astype(np.float32))
+    assert diff.max() <= 0.125, float(diff.max())                    # one half ulp at 128..255
+    assert (got != exp16).mean() < 5e-3, float((got != exp16).mean())     # half is 32x finer than uint8 around 200
+
+
+@pytest.mark.parametrize("speed", [30.0, 31.7])       # integer phases (one shared table, regenerated far ahead) / fractional phases (one table per batch)
+def test_records_built_ahead_of_their_launches(dev, speed):
+    """frame_records() for several batches BEFORE the first of them runs (bench.py --tables-outside, GpuShardEngine.records):
+    every batch's scanline row-gain table must stay alive with its records — also across a forced regeneration of the
+    shared integer-phase table — and give the frames of the build-then-run order."""
+    import dataclasses
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    rs = dataclasses.replace(baseline_config(2)[0], scanline_speed_px_s=speed, warp_strength=0.0)
+    h, w, n = 72, 136, 5
+    firsts = [0, 5, 200000, 400000, 10]          # 200000 / 400000: beyond the shared table's look-ahead -> regenerated twice
+    frames = torch.from_numpy(np.stack([make_frame(h, w, seed=700 + i, kind="grad") for i in range(n)])).to(dev)
+    ref_pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
+    want = [ref_pipe.run(frames, first_index=f)[0].clone() for f in firsts]
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
+    ahead = [pipe.frame_records(f, n) for f in firsts]
+    # churn the allocator with same-sized blocks between building and running: a freed table would be handed out again
+    junk = [torch.full((n, h), float(k), dtype=torch.float32, device=dev) for k in range(64)]
+    big = [torch.zeros(200000 + h + 65536 + 16, dtype=torch.float32, device=dev) for _ in range(4)]
+    for f, recs, exp in zip(firsts, ahead, want):
+        got, _ = pipe.run(frames, first_index=f, records=recs)
+        assert torch.equal(got, exp), f
+    del junk, big

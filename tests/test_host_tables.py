@@ -193,3 +193,28 @@ def test_local_states_view():
         ls[:4]
     with pytest.raises(IndexError):
         ls[1:3]
+
+
+def test_device_state_is_an_array_like():
+    """effects.DeviceState — the float state apply_crt_effect returns for numpy frames (ref:699) — behaves as the float32
+    array it stands for: np.asarray, indexing, arithmetic, ndarray attributes; writes through it are seen when it is handed
+    back (`.tensor`).  (A CPU tensor stands in for the device tensor here.)"""
+    import torch
+    from pythoncrt_amd.effects import DeviceState, _as_device_tensor
+    ref = np.random.default_rng(3).random((5, 7, 3), dtype=np.float32)
+    st = DeviceState(torch.from_numpy(ref.copy()))
+    assert st.shape == (5, 7, 3) and st.dtype == np.float32 and st.ndim == 3 and st.size == 105 and len(st) == 5
+    assert "device-resident" in repr(st)
+    assert np.array_equal(np.asarray(st), ref) and np.asarray(st).dtype == np.float32
+    assert "materialised" in repr(st)
+    assert np.array_equal(np.asarray(st, dtype=np.float64), ref.astype(np.float64))
+    assert np.array_equal(st[1:3, 2], ref[1:3, 2]) and st[4, 6, 2] == ref[4, 6, 2]
+    assert np.array_equal(st * 2.0, ref * 2.0) and np.array_equal(1.0 - st, 1.0 - ref) and np.array_equal(-st, -ref)
+    assert np.array_equal(st + st, ref + ref) and np.array_equal(st > 0.5, ref > 0.5)
+    assert np.array_equal(np.abs(st.astype(np.float64) - 0.5), np.abs(ref.astype(np.float64) - 0.5))
+    assert float(st.mean()) == float(ref.mean()) and st.tobytes() == ref.tobytes()
+    assert np.array_equal(np.clip(st, 0.2, 0.8), np.clip(ref, 0.2, 0.8))
+    # handed back as state_prev: the tensor itself, no copy; after a write through the object, the written values
+    assert _as_device_tensor(st, torch.device("cpu"), torch.float32, None, "state_prev").data_ptr() == st.tensor.data_ptr()
+    st[0, 0, :] = 0.25
+    assert np.array_equal(st.tensor.numpy()[0, 0], np.full(3, 0.25, np.float32)) and np.array_equal(st.tensor.numpy()[1:], ref[1:])

@@ -334,6 +334,31 @@ def test_apply_crt_effect_sequence(pc, warp):
             assert np.array_equal(ug, uo) and np.array_equal(sg, so.astype(np.float32))
 
 
+def test_numpy_path_keeps_the_state_on_the_device(pc):
+    """The GUI tick's call pattern (ref:1810-1852): numpy frame in, `out, prev = apply_crt_effect(..., state_prev=prev)`.
+    The state comes back as a DeviceState — no download, no upload next tick — and the frames and states equal those of
+    the same ticks threaded through plain numpy arrays."""
+    h, w = 70, 130
+    c = dict(BASE, **FULL)
+    tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
+    s_dev = s_np = None
+    for i in range(4):
+        frame = make_frame(h, w, seed=60 + i, kind="grad")
+        kw = dict(warp_strength=0.15, noise_seed=3, frame_index=i)
+        u1, s_dev = pc.apply_crt_effect(*crt_args(frame, tm, vg, 0.4, s_dev, float(i), c), **kw)
+        u2, s2 = pc.apply_crt_effect(*crt_args(frame, tm, vg, 0.4, s_np, float(i), c), **kw)
+        s_np = np.array(s2)                                   # a plain array: uploaded again next tick
+        assert isinstance(s_dev, pc.DeviceState) and s_dev._host is None      # still device-resident
+        assert isinstance(u1, np.ndarray) and np.array_equal(u1, u2)
+        assert np.array_equal(np.asarray(s_dev.tensor.cpu()), s_np)
+    assert np.array_equal(np.asarray(s_dev), s_np) and s_dev.shape == (h, w, 3) and s_dev.dtype == np.float32
+    # a state of another size (ref:689-690) through the same object
+    f2 = make_frame(48, 64, seed=70)
+    u3, s3 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_dev, 0.0, c))
+    u4, s4 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_np, 0.0, c))
+    assert np.array_equal(u3, u4) and np.array_equal(np.asarray(s3), np.asarray(s4))
+
+
 def test_tensor_in_tensor_out_and_purity(pc):
     h, w = 48, 64
     frame = make_frame(h, w, seed=40)
@@ -424,7 +449,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
     frame = make_frame(h, w, seed=60, kind="grad")
     tm, vg = pc.make_triad_mask(h, w, 0.35, 0.5), pc.make_vignette(h, w, 0.25)
     outs = {}
-    for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}),
+    for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("cc_no_ct", {"FORCE_CC": 1, "NO_CT": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}),
                        ("split", {"SPLIT_FROM": 0}), ("split_plane", {"SPLIT_FROM": 0, "SPLIT_SRC_PLANE": 1})):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
@@ -452,9 +477,55 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(keep.cpu().numpy())      # the per-frame states the sharded render's fix-up reads (written even when a run keeps its state in registers)
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("cc", "no_cc", "runtime_flags", "generic", "split", "split_plane"):
+    for name in ("cc", "cc_no_ct", "no_cc", "runtime_flags", "generic", "split", "split_plane"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
+
+
+@pytest.mark.parametrize("triad", [(0.35, 0.5), (0.35, 0.0), (0.5, 1.0), (0.2, 2.0), (1.0, 0.7)])
+@pytest.mark.parametrize("hw", [(40, 700), (90, 130), (33, 64), (20, 1)])
+def test_composite_triad_tables(pc, triad, hw, monkeypatch):
+    """k_phosphor_ct gathers lut_inv[idx(lut_g[i] * m)] from ONE table per mask value where a strip's mask has at most the two
+    tabulated values, and runs the two-LUT form elsewhere (border columns of a softened mask, a three-valued mask): interior
+    strips, edge strips, partial last strips and masks of 2 / 3 / many values against the oracle (bit-exact: ref:246-263) and
+    against k_phosphor_cc, for pre-warp launches (warp on) of several radii."""
+    from pythoncrt_amd import effects
+    h, w = hw
+    frame = make_frame(h, w, seed=77, kind="grad")
+    got = {}
+    for name, opts in (("ct", {"FORCE_CC": 1}), ("cc", {"FORCE_CC": 1, "NO_CT": 1})):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+        effects._tls.engines = {}
+        res = []
+        for sigma in (3.0, 1.2, 4.0):
+            c = dict(BASE, **dict(FULL, triad=triad, bloom_sigma=sigma))
+            tm = pc.make_triad_mask(h, w, *triad)
+            vg = pc.make_vignette(h, w, c["vignette"])
+            a = (frame, c["scanline_strength"], tm, 2.2, False, c["aberration_px"], sigma, c["bloom_strength"], 0.0, c["noise_strength"], vg,
+                 2.0, 1.25, False, 1, 0, 0.0)
+            res.append(pc.apply_static_effects(*a, noise_seed=11, frame_index=2, warp_strength=0.15))      # pre-warp image parked -> cc / ct
+        got[name] = res
+    effects._tls.engines = {}
+    for x, y in zip(got["ct"], got["cc"]):
+        assert np.array_equal(x, y)
+    # and the no-warp float image of the same chain against the oracle, bit for bit (the pre-warp image itself)
+    monkeypatch.setattr(effects, "DEBUG_OPTIONS", {"FORCE_CC": 1})
+    effects._tls.engines = {}
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rs = RenderSettings(fast_bloom=False, bloom_sigma=3.0, pixel_size=1, persistence=0.5, triad_strength=triad[0], triad_softness=triad[1])     # persistence: the chain parks a pre-warp image
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
+    clip = np.stack([make_frame(h, w, seed=79 + i, kind="grad") for i in range(3)])
+    out, _ = pipe.run(torch.from_numpy(clip).to(dev), first_index=1)
+    gpl = _export_planes(pipe, 5, 1, 3, h, w)
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+                                          "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")}
+    exp, _ = orc.process_frames(list(clip), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength, noise_planes=gpl, first_index=1)
+    assert np.array_equal(out[0].cpu().numpy(), exp[0])            # frame 0 passes through unblended: the pre-warp image quantised, bit-exact
+    d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    effects._tls.engines = {}
 
 
 def test_sharded_persistence_pieces_on_gpu():

@@ -23,6 +23,28 @@ def cost(m):
         if m.startswith(k):
             return v
     return 0.0
+def static_mix(path):
+    """{mangled kernel name: (VALU instructions, weighted VALU cycles)} over the whole body of every function of an ISA listing
+    (hipcc -S --cuda-device-only): the static instruction mix, used by tools/summarise_profiles.py to turn SQ_INSTS_VALU into
+    cost-weighted SIMD cycles (average cycles per VALU wave-instruction of that kernel)."""
+    out, name, n, cyc = {}, None, 0, 0.0
+    for l in open(path).read().splitlines():
+        if l and not l[0].isspace() and l.rstrip().endswith(":") and not l.startswith((".", ";")):
+            name, n, cyc = l.rstrip()[:-1], 0, 0.0
+            continue
+        if l.startswith(".Lfunc_end") and name:
+            out[name] = (n, cyc)
+            name = None
+            continue
+        if name is None:
+            continue
+        t = l.strip().split()
+        if not t or t[0].startswith((".", ";")) or t[0].endswith(":"):
+            continue
+        if t[0].startswith("v_"):
+            n += 1
+            cyc += cost(t[0])
+    return out
 def main():
     path, name = sys.argv[1], sys.argv[2]
     lines = open(path).read().splitlines()
@@ -53,4 +75,5 @@ def main():
         print(f"      {m:22s} x{hist[m]:4d}  {c:6.0f}")
     other = {m: h for m, h in hist.items() if not m.startswith("v_")}
     print("   non-VALU:", ", ".join(f"{m} x{h}" for m, h in sorted(other.items(), key=lambda kv: -kv[1])[:14]))
-main()
+if __name__ == "__main__":
+    main()

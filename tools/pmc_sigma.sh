@@ -7,7 +7,10 @@ run() { timeout -k 10 200 rocprofv3 --pmc $2 --output-format csv -d $OUT/${TAG}_
 run a "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU" "$@"
 run b "SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_IFETCH SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAVE_CYCLES" "$@"
 run e "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "$@"
-run f "FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE" "$@"
+# FETCH_SIZE costs 3 of the 4 TCC counter slots and WRITE_SIZE 2 (MI355X_MICROARCH.md, rocprofv3 PMC slots): one pass each —
+# asked for together rocprofv3 aborts with "Request exceeds the capabilities of the hardware to collect" (error 38)
+run f "FETCH_SIZE GRBM_GUI_ACTIVE" "$@"
+run w "WRITE_SIZE" "$@"
 python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

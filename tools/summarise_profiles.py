@@ -55,7 +55,7 @@ with open(f"profiles/{tag}_fetch_calibration.txt", "w") as f:
             f.write(f"  {k:8s} read {known[k] / 1e6:9.1f} MB   FETCH_SIZE reports {calib[n] / 1e6:9.1f} MB   ratio {ratio[k]:.3f}\n")
     f.write("bench.py's roofline.traffic divides a kernel's reported FETCH_SIZE by the ratio of its load shape (a ratio within 5 % of 1 is taken as 1).\n")
 fix = lambda r: 1.0 if (r is None or abs(r - 1.0) < 0.05 or r <= 0) else 1.0 / r
-fetch_fix = {"k_warp": fix(ratio.get("k_px12")), "k_phosphor": fix(ratio.get("k_byte3"))}
+fetch_fix = {"k_warp": fix(ratio.get("k_px12")), "k_phosphor": fix(ratio.get("k_byte3")), "k_bloom_pass": fix(ratio.get("k_byte3"))}
 
 # ---- frames per launch of each kernel class, from the bench line of the same collection (PMC values are per launch) ------
 fpl, bench = {}, {}
@@ -63,7 +63,7 @@ if os.path.exists(f"gpurun_out/{tag}_bench.json"):
     bench = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])
     fpl = {k: v["frames_per_launch"] for k, v in bench.get("roofline", {}).get("kernels", {}).items()}
     shutil.copy(f"gpurun_out/{tag}_bench.json", f"profiles/{tag}_bench.json")
-cls = lambda name: "k_phosphor" if ("k_phosphor" in name or "k_point" in name or "k_half" in name) else "k_warp"
+cls = lambda name: "k_bloom_pass" if ("k_half" in name or "k_sb_" in name) else "k_phosphor" if ("k_phosphor" in name or "k_point" in name) else "k_warp"
 import bench as bench_mod      # source_hash(): sha1 of the kernel sources
 src = bench_mod.source_hash()
 raw = sum((d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls(k), 1.0) for k, d in pmc.items())
@@ -76,12 +76,56 @@ tj[cfg] = {"bytes_per_frame_as_reported": int(raw), "bytes_per_frame_corrected":
            "per_launch_as_reported": {k: dict({c: int(v * 1024) for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")},
                                               frames_per_launch=fpl.get(cls(k), 1.0)) for k, d in pmc.items()}}
 json.dump(tj, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
-# VALU wave-instructions per frame + the clock the run held (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+# VALU wave-instructions per frame, cost-weighted by the static instruction mix of each kernel's ISA, the LDS pipe's share, and
+# how the dominant kernel's waves spend their time
+import subprocess, tempfile
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_cost
+from pythoncrt_amd import _lib as _build
+
+
+def kernel_avg_cost():
+    """{demangled kernel name: average measured issue cycles per VALU wave-instruction} for the kernels the PMC passes saw."""
+    R = next((int(m.group(1)) for k in pmc for m in [re.search(r"k_phosphor_(?:cc|rr)<(\d+)", k)] if m), 9)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for src, extra in (("crtfx_rr.hip", [f"-DRR_R={R}"]), ("crtfx.hip", [])):
+            asm = os.path.join(td, src + ".s")
+            subprocess.run(["hipcc", *_build.HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", _build.CSRC, *extra, "-S", "--cuda-device-only",
+                            os.path.join(_build.CSRC, src), "-o", asm], check=True)
+            mix = isa_cost.static_mix(asm)
+            names = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(mix), capture_output=True, text=True).stdout.splitlines()
+            for mangled, dem in zip(mix, names):
+                n, cyc = mix[mangled]
+                if n:
+                    out[dem.split("(")[0].replace("void ", "")] = cyc / n
+    return out
+
+
+avg = kernel_avg_cost()
+cost_of = lambda k: avg.get(k) or next((v for n, v in avg.items() if n.startswith(k.split("<")[0])), 2.9)
 valu = sum(d.get("SQ_INSTS_VALU", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+valu_w = sum(d.get("SQ_INSTS_VALU", 0) * cost_of(k) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+lds_act = sum(d.get("SQ_LDS_IDX_ACTIVE", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+lds_bc = sum(d.get("SQ_LDS_BANK_CONFLICT", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
+domk = max(pmc, key=lambda k: pmc[k].get("SQ_WAVE_CYCLES", 0)) if pmc else None
+dom_wave = dom_lds = None
+if domk:
+    d = pmc[domk]
+    wc = d.get("SQ_WAVE_CYCLES", 0) or 1.0
+    dom_wave = {"kernel": domk, "parked_SQ_WAIT_ANY": round(d.get("SQ_WAIT_ANY", 0) / wc, 3), "issue_stalled_SQ_WAIT_INST_ANY": round(d.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                "issuing_SQ_ACTIVE_INST_ANY": round(d.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3)}
+    if d.get("GRBM_GUI_ACTIVE"):
+        dom_lds = round(d.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * d["GRBM_GUI_ACTIVE"] / 8), 4)      # GRBM_GUI_ACTIVE is summed over the 8 XCDs
 vj = json.load(open("profiles/valu.json")) if os.path.exists("profiles/valu.json") else {}
-vj[cfg] = {"valu_wave_insts_per_frame": int(valu), "clock_ghz": 2.4, "source_hash": src, "tag": tag,
+vj[cfg] = {"valu_wave_insts_per_frame": int(valu), "valu_cost_weighted_cycles_per_frame": int(valu_w),
+           "valu_avg_cycles_per_inst": {k: round(cost_of(k), 3) for k in pmc},
+           "lds_idx_active_cycles_per_frame": int(lds_act), "lds_bank_conflict_cycles_per_frame": int(lds_bc),
+           "dominant_lds_pipe_frac": dom_lds, "dominant_wave_time": dom_wave,
+           "clock_ghz": 2.4, "source_hash": src, "tag": tag,
+           "cost_model": "SQ_INSTS_VALU x the kernel's average issue cycles per VALU wave-instruction: static mix of its ISA (tools/isa_cost.py) priced with profiles/r02_valu_cost.txt",
            "per_launch": {k: {c: d[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
-                                                "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES") if c in d} for k, d in pmc.items()}}
+                                                "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE") if c in d} for k, d in pmc.items()}}
 json.dump(vj, open("profiles/valu.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch_as_reported"} for k, v in tj.items()}, indent=1))
 print(open(f"profiles/{tag}_kernel_stats.csv").read() if ks else "no kernel stats")
