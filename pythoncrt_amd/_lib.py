@@ -117,6 +117,32 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     return out
 
 
+def build_variant(name: str, extra_flags, radii=(9,), main_tu: bool = False) -> str:
+    """Dev A/B builds (tools/ab_ct.sh; never the product library): build/ab/libcrtfx_<name>.so = the in-tree library's objects with the
+    translation units of `radii` (and crtfx.hip when main_tu) recompiled with extra_flags.  Load one with CRTFX_LIB=<path>."""
+    build()
+    hipcc = "hipcc" if _which("hipcc") else "/opt/rocm/bin/hipcc"
+    base = os.path.join(ROOT, "build", "obj", os.path.basename(LIB_PATH))
+    objdir = os.path.join(ROOT, "build", "obj", f"ab_{name}")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.join(ROOT, "build", "ab"), exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    objs = []
+    for r in RR_RADII:
+        o = os.path.join(base, f"crtfx_rr_{r}.o")
+        if r in radii:
+            o = os.path.join(objdir, f"crtfx_rr_{r}.o")
+            subprocess.run([hipcc, *HIPCC_FLAGS, *extra_flags, *inc, f"-DRR_R={r}", "-c", os.path.join(CSRC, "crtfx_rr.hip"), "-o", o], check=True)
+        objs.append(o)
+    main = os.path.join(base, "crtfx.o")
+    if main_tu:
+        main = os.path.join(objdir, "crtfx.o")
+        subprocess.run([hipcc, *HIPCC_FLAGS, *extra_flags, *inc, "-c", os.path.join(CSRC, "crtfx.hip"), "-o", main], check=True)
+    out = os.path.join(ROOT, "build", "ab", f"libcrtfx_{name}.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, main, *objs], check=True)
+    return out
+
+
 def _which(name):
     from shutil import which
     return which(name)

@@ -36,7 +36,24 @@ namespace crtfx {
 #define CT_WAVES 5        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for, radii <= 12
 #endif
 #ifndef CT_NLUT
-#define CT_NLUT 1         // a1 of a stored byte from a 256-entry LDS table (1) or as arithmetic (0)
+#define CT_NLUT 0         // a1 of a stored byte from a 256-entry LDS table (1) or as arithmetic (0: 1 KB less LDS — 31 520 B is 25 of gfx950's
+#endif                    // 1280-byte LDS granules, five blocks per CU; with the table it is 26 granules and four)
+// CT_EXP: timing experiments of build/ab libraries (tools/ab_ct.sh), NEVER part of the product build (crtfx_rr.hip refuses it unless
+// CRTFX_TIMING_EXPERIMENT is defined too): each bit removes one part of a trip's work — the frames are then WRONG — to measure
+// what that part costs at full occupancy.  1 blur FMAs, 2 the A phase, 4 the pre-warp stores, 8 the helper wave's tiles, 16 the
+// tail behind img + s * blur, 32 the loop's barriers, 64 the centre loads, 128 the A phase's frame loads only (a1 + staging writes stay),
+// 256 the stores go to a 48 KB window of the scratch image (same instructions, no fabric traffic), 512 the A phase loads ONE dword per
+// item instead of three bytes.
+#ifndef CT_EXP
+#define CT_EXP 0
+#endif
+#if CT_EXP && !defined(CRTFX_TIMING_EXPERIMENT)
+#error "CT_EXP builds write wrong frames: timing experiments only (-DCRTFX_TIMING_EXPERIMENT)"
+#endif
+#if CT_EXP & 32
+#define CT_BARRIER() do {} while (0)
+#else
+#define CT_BARRIER() __syncthreads()
 #endif
 __host__ __device__ constexpr int ct_lds_words(int R) {
     return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + (CT_NLUT ? 256 : 0) + NB * TW * 2 + 2 * NB * TW;
@@ -98,7 +115,8 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     const bool mine = wave == 3 || !fin || cmb == P.comp_m0 || cmb == P.comp_m1;
     // block-wide vote through four words of the (still unused) grain tiles — __syncthreads_and would bring a static LDS word
     // of its own and move the dynamic block off offset 0
-    if (lane == 0) LDS_AT(lds_u32_t, GN_B + (uint32_t)wave * 4u) = __builtin_amdgcn_ballot_w64(!mine) == 0ull ? 1u : 0u;
+    const uint32_t wave_ok = __builtin_amdgcn_ballot_w64(!mine) == 0ull ? 1u : 0u;      // every lane takes part: formed outside the lane test
+    if (lane == 0) LDS_AT(lds_u32_t, GN_B + (uint32_t)wave * 4u) = wave_ok;
     __syncthreads();
     const uint32_t votes = LDS_AT(lds_u32_t, GN_B) & LDS_AT(lds_u32_t, GN_B + 4) & LDS_AT(lds_u32_t, GN_B + 8) & LDS_AT(lds_u32_t, GN_B + 12);
     const bool comp = P.triad_comp != nullptr && __builtin_amdgcn_readfirstlane((int)votes) != 0;      // block-uniform, and known to be: a scalar branch
@@ -135,11 +153,22 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int y = min(max(hb + it / SWP, 0), H - 1);                          // BORDER_REPLICATE
         const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
+#if CT_EXP & 128
+        return RawRGB{(ro + o_r) & 255u, (ro + o_g) & 255u, (ro + o_b) & 255u};
+#elif CT_EXP & 512
+        const uint32_t d = *reinterpret_cast<const uint32_t*>(F.in + ((ro + o_g) & ~3u));
+        return RawRGB{d & 255u, (d >> 8) & 255u, (d >> 16) & 255u};
+#else
         return load_raw(PIX, F.in, ro + o_r, ro + o_g, ro + o_b);
+#endif
     };
+    // a1 — u / 255.0 of a stored byte: the LDS table, or three instructions: with c_hi + c_lo = 1/255 to 48 bits,
+    // fma(f, c_hi, f * c_lo) is the correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no
+    // f / 255 lies that close to a rounding boundary: its bits beyond the mantissa repeat f's own eight; checked exhaustively on
+    // the host with exact rationals, and against k_phosphor_cc on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
     auto a1 = [&](uint32_t u) -> float {
         if constexpr (NLUT) return LDS_AT(lds_f32_t, NLUT_B + (u << 2));
-        else return norm_u8(u);
+        else { const float f = (float)u; return fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f); }
     };
     auto a_write = [&](int q, const float (&o)[3]) {
         const int it = min((q << 6) + lane, NB * SWP - 1);
@@ -167,6 +196,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         for (int qq = 0; qq < NQ; ++qq) {
             const f32x4 vv = vq[qq];
             const f32x2 vp[2] = {{vv[0], vv[1]}, {vv[2], vv[3]}};
+#if CT_EXP & 1
+            acc2[qq & 3].x += vv[0] + vv[1]; acc2[qq & 3].y += vv[2] + vv[3]; (void)vp; (void)off;
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -176,6 +208,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     else if (t >= 1 && t <= 2 * R) PK_TAPS(acc2[pp], vp[e >> 1], (e & 1) != 0, t);
                     else if (t == 2 * R + 1) acc2[pp].y = fmaf(vp[e >> 1][e & 1], taps[0], acc2[pp].y);      // tap[2R] == tap[0]
                 }
+#endif
         }
         float* hp = hrow + j * CC_HROW + 8 * g8 * 3 + c;
 #pragma unroll
@@ -190,8 +223,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             const uint32_t tsel = (cmb == P.comp_m1 && P.comp_m1 != P.comp_m0) ? LUT_B + LUT_STRIDE * 4 : LUT_B;      // this float's table (COMP)
             const uint32_t gcol8 = (uint32_t)fcol * 8u, gcol4 = (uint32_t)fcol * 4u;  // its pixel in the vignette / grain tiles
             // pre-warp image out through a buffer resource (k_phosphor_cc): offsets past the image are dropped by the hardware
-            const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(O.pre, 0, (int)((uint32_t)H * (uint32_t)W * 12u), 0x00020000);
+            // — and the resource covers this block's row segment ONLY, so rows above / below it (the first trips' and the last
+            // trip's garbage rows) fall outside by themselves: no per-row test at all
+            const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(O.pre + (size_t)y_begin * (size_t)W * 3u, 0,
+                                                                                      (int)((uint32_t)(y_end - y_begin) * (uint32_t)W * 12u), 0x00020000);
             const uint32_t row_b = fin ? (uint32_t)W * 12u : 0u;                     // bytes per pre-warp image row (this lane's stride)
+            // the frame's scanline row gains through a buffer resource too: rows outside the frame read as 0 (never consumed)
+            const __amdgpu_buffer_rsrc_t scan_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F.scan_row), 0, H * 4, 0x00020000);
             // centre samples in through a buffer resource over the frame: per-thread byte offset inside a row (a2: R from x - d,
             // B from x + d, wrapped, ref:571-577), the row's offset in an SGPR
             const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(F.in), 0, (int)((uint32_t)H * row_elems), 0x00020000);
@@ -202,7 +240,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 if (P.ab != 0 && fch != 1) xs = wrap(fch == 0 ? x - P.ab : x + P.ab, W);
                 coff = (uint32_t)xs * 3u + (uint32_t)fch;
             }
-            const float* __restrict__ scan_row = F.scan_row;
             f32x2 win2[L / 2];
 #pragma unroll
             for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
@@ -213,6 +250,10 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 f32x2 acc[NB / 2];
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) acc[jp] = f32x2{0.0f, 0.0f};
+#if CT_EXP & 1
+#pragma unroll
+                for (int i = 0; i < L; ++i) { if (i & 1) acc[(i >> 1) & 3].y += win2[i >> 1][1]; else acc[(i >> 1) & 3].x += win2[i >> 1][0]; }
+#else
 #pragma unroll
                 for (int i = 0; i < L; ++i)
 #pragma unroll
@@ -222,19 +263,31 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                         else if (t >= 1 && t <= 2 * R) PK_TAPS(acc[jp], win2[i >> 1], (i & 1) != 0, t);
                         else if (t == 2 * R + 1) acc[jp].y = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].y);       // tap[2R] == tap[0]
                     }
+#endif
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) { blur[2 * jp] = acc[jp].x; blur[2 * jp + 1] = acc[jp].y; }
 #pragma unroll
                 for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
             };
-            // the centre bytes of output rows yb .. yb + 7 (clamped into the frame: rows outside the segment are never consumed)
+            // the centre bytes of output rows yb .. yb + 7.  The whole offset rides in the VGPR operand — the hardware's range check
+            // covers the vector offset only, not the scalar one — so a row outside the frame (modulo 2^32 when it is above it)
+            // is an offset outside the resource and reads 0 instead of touching memory; those rows are never consumed
             auto centre_load = [&](int yb, uint32_t (&cb)[NB]) {
+                uint32_t vo = coff + (uint32_t)yb * row_elems;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int y = min(max(yb + j, 0), H - 1);
-                    cb[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(in_rsrc, coff, (uint32_t)y * row_elems, 0);
+#if CT_EXP & 64
+                    cb[j] = vo & 255u;
+#else
+                    cb[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(in_rsrc, vo, 0, 0);
+#endif
+                    vo += row_elems;
                 }
             };
+            // the scanline gains of rows yb .. yb + 7: lane l asks for row yb + (l & 7) — ONE load per wave and trip, one VGPR across the
+            // barrier — and the tail reads row j's gain out of lane j (v_readlane: an SGPR operand of its multiply).  Out-of-frame rows read 0.
+            const uint32_t lane7x4 = (uint32_t)(lane & 7) * 4u;
+            auto scan_load = [&](int yb) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(scan_rsrc, (uint32_t)yb * 4u + lane7x4, 0, 0); };
             // a7 for the eight rows
             auto triad = [&](float (&v)[NB]) {
                 if constexpr (COMP) {
@@ -260,17 +313,24 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b32(0u, pre_rsrc, 0xFFFFFF00u - 16u * (uint32_t)j, 0, 0);      // out of range: dropped
             CC_PRIO(CC_P_A);
             int hb = y_begin - R;
-            uint32_t off0 = fin ? (uint32_t)(y_begin - 2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R, float f), modulo 2^32 while that row is < 0
+            uint32_t cbp0 = 0u, cbp1 = 0u;               // the trip's eight centre bytes, packed (trip 0: rows above the segment, never consumed)
+            uint32_t off0 = fin ? (uint32_t)(-2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R of the segment, float f), modulo 2^32 while that row is above it
             for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b) {
                 // ---- phase 1 ----
                 const int yb = hb - NB - R;                 // first output row of block n-1 (garbage rows in trip 0)
-                uint32_t cb[NB];
-                centre_load(yb, cb);
-                float blur[NB];
-                CC_PRIO(CC_P_VH);
-                v_pass(blur);
-                CC_PRIO(CC_P_A);
+                const uint32_t slv = scan_load(yb);          // in front of the prefetch below: its wait leaves those loads in flight
+                float v[NB];
+                {
+                    float blur[NB];
+                    CC_PRIO(CC_P_VH);
+                    v_pass(blur);
+                    CC_PRIO(CC_P_A);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)         // a1 of the centre byte (v_cvt_f32_ubyteN; a2 is in the load's column); ref:611 — only v[] crosses the barrier
+                        v[j] = clip01(a1(((j < 4 ? cbp0 : cbp1) >> (8 * (j & 3))) & 255u) + P.bloom_strength * blur[j]);
+                }
                 STAMP(4);
+#if !(CT_EXP & 2)
                 {
                     float nv[AO][3];
 #pragma unroll
@@ -278,40 +338,55 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
                     for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), nv[u]);
                 }
+#endif
+                // the centre bytes of the NEXT trip's rows (L2 hits: staged a trip ago), requested IN FRONT of the prefetch and of
+                // this trip's stores: vector memory operations complete in order, so a wait for them placed behind either would
+                // also be a wait for the prefetch's HBM round trip / the stores' acknowledgements.  Packed into two registers in the tail.
+                uint32_t cb[NB];
+                centre_load(yb + NB, cb);
+                __builtin_amdgcn_sched_barrier(0);          // ... and the scheduler keeps them in front
+#if !(CT_EXP & 2)
 #pragma unroll
                 for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hb + NB, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
+#endif
                 STAMP(0);
-                __syncthreads();
+                CT_BARRIER();
                 STAMP(1);
                 // ---- phase 2: C2 of block n-1 (output rows yb + j), stage by stage over the eight rows ----
                 CC_PRIO(CC_P_C2);
                 const uint32_t gt_b = GN_B + (uint32_t)(((n & 1) ^ 1) * NB * TW * 4) + gcol4;
-                float sl[NB], gnv[NB], v[NB];
+#if !(CT_EXP & 16)
+                float gnv[NB];
                 double gv[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    sl[j] = CONST_AT(float, scan_row)[min(max(yb + j, 0), H - 1)];            // wave-uniform: s_load_dword
                     gv[j] = LDS_AT(lds_f64_t, GVIG_B + (uint32_t)(j * TW * 8) + gcol8);
                     gnv[j] = LDS_AT(lds_f32_t, gt_b + (uint32_t)(j * TW * 4));
-                    v[j] = a1(cb[j]);                                                         // a1 (a2 is in the load's column)
                 }
-#pragma unroll
-                for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);          // ref:611
                 triad(v);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const float r = clip01(v[j] * sl[j]);                                               // ref:617-624
+                    const float r = clip01(v[j] * __uint_as_float(__builtin_amdgcn_readlane(slv, j)));   // ref:617-624
                     double d = (double)r * gv[j];                                                       // ref:626-628 (gain in [0,1]: no clip)
                     d = clip01(d + (double)gnv[j]);                                                     // ref:646-647
                     v[j] = (float)d;
                 }
+#else
+                (void)gt_b; (void)slv;
+#endif
+                cbp0 = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
+                cbp1 = cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24);
                 {
                     uint32_t boff = off0;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-                        const int y = yb + j;
-                        const uint32_t oob = (y >= y_begin && y < y_end) ? 0u : 0xFFFFFFFFu;       // wave-uniform
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff | oob, 0, 0);
+#if CT_EXP & 4
+                        asm volatile("" :: "v"(v[j]), "v"(boff));
+#elif CT_EXP & 256
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, (boff < 0xF0000000u ? (boff & 0xFFFFu) : boff), 0, 0);
+#else
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff, 0, 0);
+#endif
                         boff += row_b;
                     }
                 }
@@ -320,26 +395,24 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 h_pass(wave);
                 CC_PRIO(CC_P_A);
                 STAMP(2);
-                __syncthreads();
+                CT_BARRIER();
                 STAMP(3);
             }
             // ---- drain: C1 and C2 of the last block ----
             {
                 const int yb = hb - NB - R;
-                uint32_t cb[NB];
-                centre_load(yb, cb);
+                const uint32_t slv = scan_load(yb);
                 float v[NB], blur[NB];
                 v_pass(blur);
                 __syncthreads();
                 const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) v[j] = clip01(a1(cb[j]) + P.bloom_strength * blur[j]);
+                for (int j = 0; j < NB; ++j) v[j] = clip01(a1(((j < 4 ? cbp0 : cbp1) >> (8 * (j & 3))) & 255u) + P.bloom_strength * blur[j]);
                 triad(v);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int y = yb + j;
-                    const float sl = CONST_AT(float, scan_row)[min(max(y, 0), H - 1)];
-                    const float r = clip01(v[j] * sl);
+                    const float r = clip01(v[j] * __uint_as_float(__builtin_amdgcn_readlane(slv, j)));
                     double d = (double)r * gvig[j * TW + fcol];
                     d = clip01(d + (double)gt[j * TW + fcol]);
                     if (y >= y_begin && y < y_end && fin) O.pre[((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u + (uint32_t)f] = (float)d;
@@ -363,17 +436,24 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         CC_PRIO(CC_P_HELP);
         int hb = y_begin - R;
         // a9 vignette gain of the 8 x 64 pixels of output rows yb .. yb + 7: ny^2 of a row is wave-uniform (s_load_dwordx2)
+        const __amdgpu_buffer_rsrc_t ny2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.vig_ny2), 0, H * 8, 0x00020000);
         auto vig_tile = [&](int yb) {
+            // ny^2 of rows yb .. yb + 7: 8-byte loads at wave-uniform addresses, the offset in the (range-checked) vector operand;
+            // rows outside the frame read 0 (never consumed)
+            const uint32_t vo = (uint32_t)yb * 8u;
+            uint64_t q[NB];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int y = min(max(yb + j, 0), H - 1);               // rows outside the segment: any valid row, never consumed
-                gvig[j * TW + lane] = vignette_gain(P, cnx2, CONST_AT(double, P.vig_ny2)[y]);
-            }
+            for (int j = 0; j < NB; ++j) q[j] = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(ny2_rsrc, vo + 8u * (uint32_t)j, 0, 0));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) gvig[j * TW + lane] = vignette_gain(P, cnx2, __builtin_bit_cast(double, q[j]));
         };
         for (int n = 0; n < n_iter; ++n, hb += NB) {
             // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
+#if !(CT_EXP & 8)
             vig_tile(hb - NB - R);
+#endif
             STAMP(4);
+#if !(CT_EXP & 2)
             {
                 float nv[A3R][3];
 #pragma unroll
@@ -383,10 +463,12 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             }
 #pragma unroll
             for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hb + NB, offr[u], offg[u], offb[u]);
+#endif
             STAMP(0);
-            __syncthreads();
+            CT_BARRIER();
             STAMP(1);
             // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip) ----
+#if !(CT_EXP & 8)
             float* gw = gn + (n & 1) * NB * TW;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -394,9 +476,10 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
                 gw[j * TW + lane] = z * P.noise_scale;
             }
+#endif
             STAMP(6);
             STAMP(2);
-            __syncthreads();
+            CT_BARRIER();
             STAMP(3);
         }
         vig_tile(hb - NB - R);

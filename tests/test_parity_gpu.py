@@ -354,8 +354,8 @@ def test_numpy_path_keeps_the_state_on_the_device(pc):
     assert np.array_equal(np.asarray(s_dev), s_np) and s_dev.shape == (h, w, 3) and s_dev.dtype == np.float32
     # a state of another size (ref:689-690) through the same object
     f2 = make_frame(48, 64, seed=70)
-    u3, s3 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_dev, 0.0, c))
-    u4, s4 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_np, 0.0, c))
+    u3, s3 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_dev, 0.0, c), noise_seed=3, frame_index=9)
+    u4, s4 = pc.apply_crt_effect(*crt_args(f2, pc.make_triad_mask(48, 64, 0.35, 0.5), pc.make_vignette(48, 64, 0.25), 0.4, s_np, 0.0, c), noise_seed=3, frame_index=9)
     assert np.array_equal(u3, u4) and np.array_equal(np.asarray(s3), np.asarray(s4))
 
 

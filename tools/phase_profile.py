@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): per-phase cycle shares of k_phosphor_rr from a CRTFX_STAMP diagnostic build.
 
-    hipcc ... -DCRTFX_STAMP -o build/ab/lib_stamp.so pythoncrt_amd/csrc/crtfx.hip
+    python -c "from pythoncrt_amd import _lib; _lib.build(force=True, extra_flags=['-DCRTFX_STAMP'], out='build/stamp/lib_stamp.so')"
     python tools/phase_profile.py [config] [NO_CC=1 ...]
 
-Slots: 0 A(grade->LDS) 1 barrier 2 B(H-pass) 3 barrier 4 C1(V-pass) 5 barrier 6 C2(masks+store)."""
+Slots: 0 A(grade->LDS) 1 barrier 2 B(H-pass) 3 barrier 4 C1(V-pass) 5 barrier 6 C2(masks+store).
+k_phosphor_cc / k_phosphor_ct (waves 0-2 consumers, wave 3 helper): 4 = phase 1 up to and including the V pass (helper: vignette tile),
+0 = the rest of phase 1 (A items, prefetch), 1 = wait at the first barrier, 6 = the tail C2 (helper: grain tile), 2 = H pass, 3 = wait at the
+second barrier."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CRTFX_LIB"] = os.path.join(ROOT, "build", "ab", "lib_stamp.so")
+os.environ.setdefault("CRTFX_LIB", os.path.join(ROOT, "build", "stamp", "lib_stamp.so"))
 import torch
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = torch.device("cuda", 0)
@@ -26,7 +29,7 @@ frames = torch.randint(0, 256, (2, h, w, 3), dtype=torch.uint8, device=dev)
 pipe.run(frames)
 torch.cuda.synchronize()
 dbg.zero_()
-pipe.run(frames[:1])
+pipe.run(frames)          # the planner's full launch group (4K: two frames per grid), i.e. the occupancy bench.py runs at
 torch.cuda.synchronize()
 d = dbg.cpu().view(-1, 8).double()
 d = d[d.sum(1) > 0]
