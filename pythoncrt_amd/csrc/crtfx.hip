@@ -279,6 +279,7 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
 }
 
 constexpr int CC_MIN_RADIUS = 8;
+constexpr int CT_MAX_RADIUS = 12;      // k_phosphor_ct serves the four-blocks-per-CU radii; beyond them (3 / 2 blocks per CU, register-bound) k_phosphor_cc stays
 bool use_cc(const crtfx_ctx* c, int R) {
     return c->pix_fmt == CRTFX_PIX_U8 && (c->force_cc || R >= CC_MIN_RADIUS) && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
 }
@@ -306,7 +307,7 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     // image with 32-bit byte offsets.
     bool cc = folded && !pix_fold && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
-    const bool ct = cc && !c->no_ct && c->pix_fmt == CRTFX_PIX_U8;       // the composite-table build of the same kernel (uint8 frames)
+    const bool ct = cc && !c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS;       // the dword-load / composite-table build of the same kernel (uint8 frames)
     int& seg_slot = c->seg_for[ct ? 3 : cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, ct ? 2 : cc ? 1 : 0).seg;   // planned once per (kernel build, group size)
     const int seg = seg_slot;
@@ -736,7 +737,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         const bool folded_plan = (gates_plan == SF_FULL || pix_fold_plan) && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
         const bool cc_plan = folded_plan && !pix_fold_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
-        const int cc_build = cc_plan ? ((!c->no_ct && c->pix_fmt == CRTFX_PIX_U8) ? 2 : 1) : 0;
+        const int cc_build = cc_plan ? ((!c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS) ? 2 : 1) : 0;
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_build);
         if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, c->opt_group, c->opt_group, cc_build);      // the planner's rows per block for the group size asked for
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;

@@ -1,49 +1,52 @@
-// crtfx_phosphor_ct.hip.h — k_phosphor_ct: the column-owner kernel of crtfx_phosphor.hip.h (k_phosphor_cc) with fewer LDS
-// operations per pixel and a smaller LDS footprint (round 3).  Same stage chain, same arithmetic per sample, same bits
-// (tests/test_parity_gpu.py::test_kernel_variants_agree holds the phosphor builds of a launch to identical output).
+// crtfx_phosphor_ct.hip.h — k_phosphor_ct: the column-owner kernel of crtfx_phosphor.hip.h (k_phosphor_cc) rebuilt around what
+// round 3's ablation runs showed bounds it: VECTOR-MEMORY INSTRUCTIONS, not VALU or LDS.  Same stage chain, same arithmetic per
+// sample, same bits (tests/test_parity_gpu.py::test_kernel_variants_agree, ::test_composite_triad_tables).
 // (One of the parts of crtfx_kernels.hip.h.)
 //
-// What k_phosphor_cc's counters said (profiles/r02_z_pmc.json): the LDS pipe is busy 58 % of the kernel, 38 % of that
-// on bank conflicts of the three random table gathers per sample (a1 table, lut_g, lut_inv), SQ_WAIT_INST_LDS 21.9 M.
-// Per consumer wave and trip of eight rows the tail issued 56 LDS reads; here it issues 24:
+// The measurements (profiles/r03_ct_ablation.txt; 4K, R = 9, us per 2-frame launch, k_phosphor_cc = 128): removing the blur's
+// FMAs saves 4 %, the whole pointwise tail 0 %, the barriers 3 % — but the A phase's frame loads alone 11 %, the pre-warp
+// stores 16 % (10 % of it fabric traffic) and eight byte loads per wave and trip for the centre samples 6 %.  A block issued
+// 131 vector-memory instructions per trip of eight rows — 99 of them single-byte loads of the frame, three per staged pixel,
+// because R and B are fetched at a shifted column (a2) — and a CU takes one per ~13 cycles: four resident blocks keep its
+// memory pipeline busy for most of a trip while VALU and LDS idle.  So:
 //
-//   * composite triad table.  With preserve-luma off the two LUT steps of _apply_triad_mask (ref:246-263),
+//   * the A phase loads DWORDS.  A strip's staged row segment (64 + 2 pad pixels, R and B displaced by the aberration) is one
+//     contiguous window of the frame row: (88 + 2|d|) * 3 bytes = 68 aligned dwords at R = 9, d = 1.  A lane loads one dword
+//     of one row (9 wave-loads per trip instead of 33 + 66), converts its four bytes (v_cvt_f32_ubyte0..3 — the byte select
+//     is free — and a two-instruction exact u / 255, see a1) and scatters them to the (channel, column) slots of the staging
+//     tile they belong to; the slots are block-invariant and sit in registers.  The raw dword also goes into an LDS ring of
+//     frame-row windows (R + 16 rows), from which the tail reads its centre sample with ds_read_u8: no second fetch of the
+//     frame, no byte loads at all.  Rows need W % 4 == 0 (dword-aligned rows) and a window inside the frame: the first and last
+//     strip(s), where BORDER_REPLICATE and the aberration's wrap bend the window, run k_phosphor_cc's byte-wise A phase
+//     (a second copy of the loop, chosen per block; blocks of both kinds share a launch).
+//   * composite triad table (the same blocks).  With preserve-luma off the two LUT steps of _apply_triad_mask (ref:246-263),
 //     lut_inv[idx(lut_g[i] * m)], are a function of the index i and the thread's constant mask value m.  A softened
-//     period-3 mask has two distinct interior values for the reference's defaults (on-phosphor / off-phosphor), so the
-//     host tabulates T_m[i] = lut_inv[idx(lut_g[i] * m)] for the two most frequent mask values (crtfx_set_params:
-//     the same float32 product and truncation the kernels do — bit-identical by construction) and they take the LDS
-//     the LUT pair occupied: ONE gather instead of two, and no multiply / index arithmetic between them.  A strip with
-//     any other mask value (the replicate-border columns of a softened mask, a 3-valued mask) votes at block start and
-//     runs the two-gather form on the LUT pair — a second copy of the consumer loop, chosen per block.
-//   * the centre sample of img + s * blur comes back from the frame itself (a byte load through a raw buffer resource
-//     with the row offset in an SGPR, issued at the top of phase 1 and consumed behind the barrier; the rows were read by
-//     this block's own A phase two trips earlier, so they sit in L2) instead of being parked in an LDS ring by the A phase
-//     and re-read with ds_read_u8: no ring stores, no ring reads, 6.4 KB of LDS less.
-//   * the scanline gain of a row and the vignette's ny^2 are wave-uniform: scalar loads from the frame's tables through the
-//     constant address space (s_load_dword, SGPR operands of the multiply) instead of an LDS row table filled by the
-//     helper wave from vector loads.
-//
-// LDS per block: staging 8.6 KB + H rows 6.1 KB + two tables 8.0 KB + a1 table 1 KB + vignette tile 4 KB + two grain tiles
-// 4 KB = 31.8 KB at R = 9 (k_phosphor_cc: 38.3 KB): FIVE blocks per CU where the register budget allows (ct_min_waves).
+//     period-3 mask has two distinct interior values for the reference's defaults, so the host tabulates
+//     T_m[i] = lut_inv[idx(lut_g[i] * m)] for the two most frequent mask values (crtfx_set_params: the kernels' own float32
+//     product and truncation) and they take the LDS the LUT pair occupied: one gather instead of two.  A strip with any
+//     other mask value votes at block start and runs the two-gather form.
+//   * no vector-memory wait ever covers a store or the next trip's prefetch: the waits are counted (vmcnt) so that the
+//     eight stores and the prefetched dwords stay in flight across them — vector-memory operations complete in order, and a
+//     wait placed behind the stores would also be a wait for their acknowledgements from the fabric.
+//   * the scanline gain of a row is wave-uniform: lane l loads row yb + (l & 7) (one load per wave and trip), the tail takes
+//     row j's gain out of lane j with v_readlane (an SGPR operand of its multiply); the vignette's ny^2 likewise comes from
+//     wave-uniform buffer loads in the helper wave.  No LDS row table.
+//   * stores through a buffer resource over the block's OWN row segment: rows above / below it fall outside the resource
+//     and are dropped by the hardware — no per-row test.
 #pragma once
 #include "crtfx_phosphor.hip.h"
 
 namespace crtfx {
 
-#define CONST_AT(T, p) ((const __attribute__((address_space(4))) T*)(uintptr_t)(p))      // wave-uniform index -> s_load
-
 #ifndef CT_WAVES
-#define CT_WAVES 5        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for, radii <= 12
+#define CT_WAVES 4        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for, radii <= 12
 #endif
-#ifndef CT_NLUT
-#define CT_NLUT 0         // a1 of a stored byte from a 256-entry LDS table (1) or as arithmetic (0: 1 KB less LDS — 31 520 B is 25 of gfx950's
-#endif                    // 1280-byte LDS granules, five blocks per CU; with the table it is 26 granules and four)
-// CT_EXP: timing experiments of build/ab libraries (tools/ab_ct.sh), NEVER part of the product build (crtfx_rr.hip refuses it unless
+// CT_EXP: timing experiments of build/ab libraries (tools/ab_ct.sh), NEVER part of the product build (refused unless
 // CRTFX_TIMING_EXPERIMENT is defined too): each bit removes one part of a trip's work — the frames are then WRONG — to measure
 // what that part costs at full occupancy.  1 blur FMAs, 2 the A phase, 4 the pre-warp stores, 8 the helper wave's tiles, 16 the
-// tail behind img + s * blur, 32 the loop's barriers, 64 the centre loads, 128 the A phase's frame loads only (a1 + staging writes stay),
-// 256 the stores go to a 48 KB window of the scratch image (same instructions, no fabric traffic), 512 the A phase loads ONE dword per
-// item instead of three bytes.
+// tail behind img + s * blur, 32 the loop's barriers, 128 the A phase's frame loads only (conversion + staging writes stay),
+// 256 the stores go to a 64 KB window of the scratch image (same instructions, no fabric traffic), 1024 every strip takes the
+// byte-wise A phase and the two-gather triad (the slow path).
 #ifndef CT_EXP
 #define CT_EXP 0
 #endif
@@ -55,8 +58,12 @@ namespace crtfx {
 #else
 #define CT_BARRIER() __syncthreads()
 #endif
+// a frame-row window in dwords, at most: (staged pixels + 2 * 8 of aberration) * 3 bytes, + 3 of alignment slack, + 1
+__host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3 + 5) / 4 + 1; }
+__host__ __device__ constexpr int ct_ring_words(int R) { return rr_cring(R) * (ct_ndmax(R) > TW ? ct_ndmax(R) : TW); }
+// LDS words: staging, one H-row tile, two tables, the ring of frame-row windows, vignette tile (f64), two grain tiles (f32)
 __host__ __device__ constexpr int ct_lds_words(int R) {
-    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + (CT_NLUT ? 256 : 0) + NB * TW * 2 + 2 * NB * TW;
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + NB * TW * 2 + 2 * NB * TW;
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 12 ? CT_WAVES : (R <= 20 ? 3 : 2); }
 
@@ -67,7 +74,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     KParams P = Pin;
     P.flags = SF_FULL;
     P.pix = 0;
-    constexpr int PIX = 0;
     extern __shared__ float4 smem4[];
     float* smem = reinterpret_cast<float*>(smem4);
     constexpr int R = RT;
@@ -75,23 +81,30 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr int SWP = rr_swp(R);
     constexpr int SWS = cc_sws(R);
     constexpr int L = 2 * R + NB;
-    constexpr int NA = (NB * SWP + 63) / 64;             // A-phase wave-items
+    constexpr int CR = rr_cring(R);
+    constexpr int HT = NB * CC_HROW;
+    // byte-wise A phase (edge strips): wave-items of 64 staged pixels, as in k_phosphor_cc
+    constexpr int NA = (NB * SWP + 63) / 64;
     constexpr int A3 = CC_A3(NA);                        // ... of the helper wave (the last A3 items)
     constexpr int AO = (NA - A3 + 2) / 3;                // ... of each consumer wave (items wave, wave + 3, ...)
-    constexpr int HT = NB * CC_HROW;
-    constexpr bool NLUT = CT_NLUT != 0;
+    // dword A phase: wave-items of 64 (row, dword) pairs of the NB row windows
+    constexpr int NDMAX = ct_ndmax(R);
+    constexpr int RS = NDMAX > TW ? NDMAX : TW;          // ring row stride in dwords (the byte-wise path parks TW packed pixels per row)
+    constexpr int NQF = (NB * NDMAX + 63) / 64;
+    constexpr int FO = (NQF + 4) / 5;                    // ... of each consumer wave (items wave, wave + 3, ...)
+    constexpr int FH = NQF - 3 * FO > 0 ? NQF - 3 * FO : 0;      // ... of the helper wave (the last ones: mostly past a short window's end)
     // LDS map, byte offsets from 0 (LDS_AT)
     constexpr uint32_t STG_B = 0;                                            // [NB][3][SWS] float      staging tile
     constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   composite tables T_m0, T_m1 — or lut_g, lut_inv
-    constexpr uint32_t NLUT_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [256] float             u / 255.0
-    constexpr uint32_t GVIG_B = NLUT_B + (NLUT ? 256 * 4 : 0);               // [NB][TW] double         vignette gain tile
+    constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [CR][RS] dword          frame-row windows (fast path) / packed centre pixels (byte-wise path)
+    constexpr uint32_t GVIG_B = RING_B + ct_ring_words(R) * 4;               // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
     static_assert(GN_B + 2 * NB * TW * 4 == (uint32_t)ct_lds_words(R) * 4, "LDS map and ct_lds_words disagree");
+    static_assert(SWS - SWP >= 4, "the dword A phase parks the bytes it does not stage in the four pad floats behind a staging plane");
     float* stg = smem;
     float* hrow = smem + HROW_B / 4;
     float* lut = smem + LUT_B / 4;
-    float* nlut = smem + NLUT_B / 4;
     double* gvig = reinterpret_cast<double*>(smem + GVIG_B / 4);
     float* gn = smem + GN_B / 4;
     if ((uint32_t)(uintptr_t)(lds_f32_t*)smem != 0u) __builtin_trap();      // LDS_AT assumes the dynamic block starts at 0
@@ -105,27 +118,36 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     const int y_begin = blockIdx.y * seg_rows;
     const int y_end = min(H, y_begin + seg_rows);
     if (y_begin >= H) return;
+    const uint32_t row_elems = (uint32_t)W * 3u;
 
-    // ---- which triad form this strip runs: every mask value of its 192 floats one of the two tabulated ones? ----------------
+    // ---- which form this strip runs ---------------------------------------------------------------------------------------------
+    // (1) every mask value of its 192 floats one of the two tabulated ones?  A block-wide vote through four words of the (still
+    // unused) grain tiles — __syncthreads_and would bring a static LDS word of its own and move the dynamic block off offset 0
     const int f = wave * 64 + lane;                      // consumer threads: float f of the strip's interleaved RGB row segment
     const int fcol = (f < 192 ? f : 0) / 3, fch = (f < 192 ? f : 0) - 3 * fcol;
     const bool fin = x0 + fcol < W;
     const float cm = P.triad_row[min(x0 + fcol, W - 1) * 3 + fch];           // a7 mask of this float
     const uint32_t cmb = __float_as_uint(cm);
     const bool mine = wave == 3 || !fin || cmb == P.comp_m0 || cmb == P.comp_m1;
-    // block-wide vote through four words of the (still unused) grain tiles — __syncthreads_and would bring a static LDS word
-    // of its own and move the dynamic block off offset 0
     const uint32_t wave_ok = __builtin_amdgcn_ballot_w64(!mine) == 0ull ? 1u : 0u;      // every lane takes part: formed outside the lane test
     if (lane == 0) LDS_AT(lds_u32_t, GN_B + (uint32_t)wave * 4u) = wave_ok;
     __syncthreads();
     const uint32_t votes = LDS_AT(lds_u32_t, GN_B) & LDS_AT(lds_u32_t, GN_B + 4) & LDS_AT(lds_u32_t, GN_B + 8) & LDS_AT(lds_u32_t, GN_B + 12);
-    const bool comp = P.triad_comp != nullptr && __builtin_amdgcn_readfirstlane((int)votes) != 0;      // block-uniform, and known to be: a scalar branch
+    // (2) the row window inside the frame (no BORDER_REPLICATE clamp, no aberration wrap) and dword-aligned rows?
+    const int aab = P.ab < 0 ? -P.ab : P.ab;
+    const int px_lo = x0 - pad - aab, px_hi = x0 - pad + SWP - 1 + aab;      // first / last frame column the window touches
+    const bool interior = px_lo >= 0 && px_hi <= W - 1 && (W & 3) == 0;
+    bool fast = P.triad_comp != nullptr && __builtin_amdgcn_readfirstlane((int)votes) != 0 && interior;      // block-uniform, and known to be: a scalar branch
+#if CT_EXP & 1024
+    fast = false;
+#endif
+    const uint32_t a_lo = ((uint32_t)(px_lo > 0 ? px_lo : 0) * 3u) & ~3u;    // the window's first byte in a frame row, dword-aligned
+    const int ND = interior ? (int)(((uint32_t)px_hi * 3u + 2u - a_lo) / 4u) + 1 : 1;      // its dwords (<= NDMAX)
     {
-        const float* t0 = comp ? P.triad_comp : P.lut_g;
-        const float* t1 = comp ? P.triad_comp + LUT_N : P.lut_inv;
+        const float* t0 = fast ? P.triad_comp : P.lut_g;
+        const float* t1 = fast ? P.triad_comp + LUT_N : P.lut_inv;
         for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = t0[i]; lut[LUT_STRIDE + i] = t1[i]; }
     }
-    if constexpr (NLUT) { if (tid < 256) nlut[tid] = norm_u8((uint32_t)tid); }
     const float* taps = P.taps;
     // the taps as R + 1 aligned SGPR pairs (tap[2m], tap[2m+1]); see k_phosphor_cc
     unsigned long long tp[R + 1];
@@ -133,7 +155,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     for (int m = 0; m <= R; ++m)
         tp[m] = (unsigned long long)__float_as_uint(taps[2 * m]) | ((unsigned long long)(2 * m + 1 <= 2 * R ? __float_as_uint(taps[2 * m + 1]) : 0u) << 32);
 #define PK_TAPS(acc, wpair, whigh, t) pk_fma_bcast(acc, wpair, whigh, ((t) & 1) ? tp[((t) - 1) / 2] : tp[(2 * R - (t)) / 2], ((t) & 1) != 0)
-    const uint32_t row_elems = (uint32_t)W * 3u;
     const int n_iter = (y_end + R - (y_begin - R) + NB - 1) / NB;                    // loop trips (same for both roles)
 #ifdef CRTFX_STAMP
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
@@ -141,6 +162,12 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #endif
 
     // ---- pieces shared by the two roles ---------------------------------------------------------------------------------------
+    // a1 — u / 255.0 of a stored byte in three instructions: with c_hi + c_lo = 1/255 to 48 bits, fma(f, c_hi, f * c_lo) is the
+    // correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no f / 255 lies that close to a
+    // rounding boundary: its bits beyond the mantissa repeat f's own eight; checked with exact rationals on the host, and
+    // against k_phosphor_cc's table of IEEE quotients on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
+    auto a1 = [&](uint32_t u) -> float { const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f); };
+    // -- byte-wise A phase (k_phosphor_cc's): source element offsets of wave-item q for this lane (block-invariant)
     auto a_offsets = [&](int q, uint32_t& o_r, uint32_t& o_g, uint32_t& o_b) {
         const int it = min((q << 6) + lane, NB * SWP - 1);     // lanes past the tile's last item redo it (same loads, same LDS stores)
         const int i = it - (it / SWP) * SWP;
@@ -155,26 +182,56 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
 #if CT_EXP & 128
         return RawRGB{(ro + o_r) & 255u, (ro + o_g) & 255u, (ro + o_b) & 255u};
-#elif CT_EXP & 512
-        const uint32_t d = *reinterpret_cast<const uint32_t*>(F.in + ((ro + o_g) & ~3u));
-        return RawRGB{d & 255u, (d >> 8) & 255u, (d >> 16) & 255u};
 #else
-        return load_raw(PIX, F.in, ro + o_r, ro + o_g, ro + o_b);
+        return load_raw(0, F.in, ro + o_r, ro + o_g, ro + o_b);
 #endif
     };
-    // a1 — u / 255.0 of a stored byte: the LDS table, or three instructions: with c_hi + c_lo = 1/255 to 48 bits,
-    // fma(f, c_hi, f * c_lo) is the correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no
-    // f / 255 lies that close to a rounding boundary: its bits beyond the mantissa repeat f's own eight; checked exhaustively on
-    // the host with exact rationals, and against k_phosphor_cc on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
-    auto a1 = [&](uint32_t u) -> float {
-        if constexpr (NLUT) return LDS_AT(lds_f32_t, NLUT_B + (u << 2));
-        else { const float f = (float)u; return fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f); }
-    };
-    auto a_write = [&](int q, const float (&o)[3]) {
+    auto a_write = [&](int q, int crow0, RawRGB v) {
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int j = it / SWP, i = it - j * SWP;
+        if (i >= pad && i < pad + TW) {                    // a centre pixel: parked as packed bytes for the tail
+            int cr = crow0 + j;
+            cr = cr >= CR ? cr - CR : cr;
+            LDS_AT(lds_u32_t, RING_B + (uint32_t)((cr * RS + (i - pad)) * 4)) = v.r | (v.g << 8) | (v.b << 16);
+        }
         float* sp = stg + (j * 3) * SWS + i;
-        sp[0] = o[0]; sp[SWS] = o[1]; sp[2 * SWS] = o[2];
+        sp[0] = a1(v.r); sp[SWS] = a1(v.g); sp[2 * SWS] = a1(v.b);
+    };
+    // -- dword A phase: item = (row j, dword k of the row window); block-invariant per lane: the dword's byte offset in a frame row,
+    // its row, and the staging slots of its four bytes (a byte that belongs to no staged sample goes to a pad float behind its plane)
+    struct FItem { uint32_t ld, j, s[4]; };
+    auto f_setup = [&](int q) -> FItem {
+        FItem it;
+        const int idx = min((q << 6) + lane, NB * ND - 1);      // items past the window's end redo the last one
+        const int j = idx / ND, k = idx - j * ND;
+        it.ld = a_lo + 4u * (uint32_t)k;
+        it.j = (uint32_t)j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = (int)it.ld + e;                  // byte of the frame row
+            const int p = b / 3, c = b - 3 * p;            // its pixel and channel
+            const int i = p - (x0 - pad) + (c == 0 ? P.ab : (c == 2 ? -P.ab : 0));      // staged pixel i takes R from column x - d and B from x + d (ref:573-575)
+            const bool ok = i >= 0 && i < SWP;
+            it.s[e] = STG_B + (uint32_t)(((j * 3 + c) * SWS + (ok ? i : SWP + e)) * 4);
+        }
+        return it;
+    };
+    auto f_load = [&](const FItem& it, int hb) -> uint32_t {
+        const int y = min(max(hb + (int)it.j, 0), H - 1);                         // BORDER_REPLICATE
+#if CT_EXP & 128
+        return (uint32_t)y * row_elems + it.ld;
+#else
+        return *reinterpret_cast<const uint32_t*>(F.in + ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));
+#endif
+    };
+    auto f_write = [&](const FItem& it, int crow0, uint32_t d) {
+        int cr = crow0 + (int)it.j;
+        cr = cr >= CR ? cr - CR : cr;
+        LDS_AT(lds_u32_t, RING_B + (uint32_t)__umul24((uint32_t)cr, (uint32_t)(RS * 4)) + (it.ld - a_lo)) = d;      // the raw window dword
+        LDS_AT(lds_f32_t, it.s[0]) = a1(d & 255u);
+        LDS_AT(lds_f32_t, it.s[1]) = a1((d >> 8) & 255u);
+        LDS_AT(lds_f32_t, it.s[2]) = a1((d >> 16) & 255u);
+        LDS_AT(lds_f32_t, it.s[3]) = a1(d >> 24);
     };
     // H pass of the staging tile by a consumer wave (k_phosphor_cc's: 8 adjacent outputs per lane, lanes mapped through the
     // hardware's 16-lane ds_read_b128 groups; taps left to right, fused — the oracle's RowFilter order)
@@ -217,32 +274,31 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 
     if (wave < 3) {
         // =============================== CONSUMER: waves 0-2 ================================================================
-        // COMP: composite tables in LDS (one gather) or the LUT pair (two gathers and the mask multiply between them)
-        auto consumer = [&](auto comp_c) __attribute__((always_inline)) {
-            constexpr bool COMP = decltype(comp_c)::value;
-            const uint32_t tsel = (cmb == P.comp_m1 && P.comp_m1 != P.comp_m0) ? LUT_B + LUT_STRIDE * 4 : LUT_B;      // this float's table (COMP)
+        // thread f owns float f of the strip's 192-float interleaved RGB row segment (pixel f / 3, channel f % 3) in the V pass AND
+        // in the pointwise tail, eight rows at a time.  FAST: dword A phase + frame-row ring + composite tables; else the byte-wise
+        // A phase, the packed-pixel ring and the LUT pair (two gathers and the mask multiply between them).
+        auto consumer = [&](auto fast_c) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            constexpr int NI = FAST ? FO : AO;           // this wave's A items per trip
+            const uint32_t tsel = (cmb == P.comp_m1 && P.comp_m1 != P.comp_m0) ? LUT_B + LUT_STRIDE * 4 : LUT_B;      // this float's table (FAST)
             const uint32_t gcol8 = (uint32_t)fcol * 8u, gcol4 = (uint32_t)fcol * 4u;  // its pixel in the vignette / grain tiles
-            // pre-warp image out through a buffer resource (k_phosphor_cc): offsets past the image are dropped by the hardware
-            // — and the resource covers this block's row segment ONLY, so rows above / below it (the first trips' and the last
-            // trip's garbage rows) fall outside by themselves: no per-row test at all
+            // pre-warp image out through a buffer resource over this block's row segment: one SGPR descriptor + a 32-bit byte
+            // offset per store, and an offset outside the segment — rows above / below it (the first trips' and the last trip's
+            // garbage rows), lanes right of the frame (offset pinned out of range) — is DROPPED by the hardware's range check
             const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(O.pre + (size_t)y_begin * (size_t)W * 3u, 0,
                                                                                       (int)((uint32_t)(y_end - y_begin) * (uint32_t)W * 12u), 0x00020000);
             const uint32_t row_b = fin ? (uint32_t)W * 12u : 0u;                     // bytes per pre-warp image row (this lane's stride)
             // the frame's scanline row gains through a buffer resource too: rows outside the frame read as 0 (never consumed)
             const __amdgpu_buffer_rsrc_t scan_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F.scan_row), 0, H * 4, 0x00020000);
-            // centre samples in through a buffer resource over the frame: per-thread byte offset inside a row (a2: R from x - d,
-            // B from x + d, wrapped, ref:571-577), the row's offset in an SGPR
-            const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(F.in), 0, (int)((uint32_t)H * row_elems), 0x00020000);
-            uint32_t coff;
-            {
-                const int x = min(x0 + fcol, W - 1);
-                int xs = x;
-                if (P.ab != 0 && fch != 1) xs = wrap(fch == 0 ? x - P.ab : x + P.ab, W);
-                coff = (uint32_t)xs * 3u + (uint32_t)fch;
-            }
+            // this float's centre byte inside a ring row: FAST — its byte of the frame-row window (a2: R from column x - d, B from
+            // x + d; the window is inside the frame, no wrap); else byte fch of packed pixel fcol
+            const uint32_t cpl = FAST ? (uint32_t)((x0 + fcol + (fch == 0 ? -P.ab : (fch == 2 ? P.ab : 0))) * 3 + fch) - a_lo
+                                      : (uint32_t)(fcol * 4 + fch);
             f32x2 win2[L / 2];
 #pragma unroll
             for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
+            // C1: append the eight H rows of the tile, form output rows j (x) and j + 1 (y) of each pair from window elements
+            // i = j .. j + 2R + 1 oldest first, shift the window down by NB
             auto v_pass = [&](float (&blur)[NB]) {
                 const float* hcol = hrow + f;
 #pragma unroll
@@ -269,28 +325,23 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
                 for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
             };
-            // the centre bytes of output rows yb .. yb + 7.  The whole offset rides in the VGPR operand — the hardware's range check
-            // covers the vector offset only, not the scalar one — so a row outside the frame (modulo 2^32 when it is above it)
-            // is an offset outside the resource and reads 0 instead of touching memory; those rows are never consumed
-            auto centre_load = [&](int yb, uint32_t (&cb)[NB]) {
-                uint32_t vo = coff + (uint32_t)yb * row_elems;
+            // a1 of the centre samples of output rows c2row0 .. + 7 of the ring (a2 is in the byte's column)
+            auto centre = [&](int c2row0, float (&v)[NB]) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-#if CT_EXP & 64
-                    cb[j] = vo & 255u;
-#else
-                    cb[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(in_rsrc, vo, 0, 0);
-#endif
-                    vo += row_elems;
+                    int cr = c2row0 + j;
+                    cr = cr >= CR ? cr - CR : cr;
+                    v[j] = a1((uint32_t)LDS_AT(lds_u8_t, RING_B + (uint32_t)(cr * RS * 4) + cpl));
                 }
             };
-            // the scanline gains of rows yb .. yb + 7: lane l asks for row yb + (l & 7) — ONE load per wave and trip, one VGPR across the
-            // barrier — and the tail reads row j's gain out of lane j (v_readlane: an SGPR operand of its multiply).  Out-of-frame rows read 0.
+            // the scanline gains of rows yb .. yb + 7: lane l asks for row yb + (l & 7) — ONE load per wave and trip, one VGPR across
+            // the barrier — and the tail reads row j's gain out of lane j (v_readlane: an SGPR operand of its multiply).  The offset
+            // rides in the VGPR operand, which the hardware range-checks: out-of-frame rows read 0 and touch no memory.
             const uint32_t lane7x4 = (uint32_t)(lane & 7) * 4u;
             auto scan_load = [&](int yb) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(scan_rsrc, (uint32_t)yb * 4u + lane7x4, 0, 0); };
             // a7 for the eight rows
             auto triad = [&](float (&v)[NB]) {
-                if constexpr (COMP) {
+                if constexpr (FAST) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) v[j] = LDS_AT(lds_f32_t, tsel + ((uint32_t)lut_index_unit(v[j]) << 2));             // ref:250-252 + :261-262 composed
                 } else {
@@ -300,54 +351,66 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     for (int j = 0; j < NB; ++j) v[j] = LDS_AT(lds_f32_t, LUT_B + LUT_STRIDE * 4 + ((uint32_t)lut_index(v[j]) << 2));   // ref:261-262
                 }
             };
-            uint32_t offr[AO], offg[AO], offb[AO];
-            RawRGB raw[AO];
+            // ---- A items of this wave ----
+            FItem fit[FAST ? FO : 1];
+            uint32_t fraw[FAST ? FO : 1];
+            uint32_t offr[FAST ? 1 : AO], offg[FAST ? 1 : AO], offb[FAST ? 1 : AO];
+            RawRGB raw[FAST ? 1 : AO];
+            if constexpr (FAST) {
 #pragma unroll
-            for (int u = 0; u < AO; ++u) a_offsets(min(wave + 3 * u, NA - A3 - 1), offr[u], offg[u], offb[u]);
+                for (int u = 0; u < FO; ++u) fit[u] = f_setup(wave + 3 * u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < AO; ++u) a_offsets(min(wave + 3 * u, NA - A3 - 1), offr[u], offg[u], offb[u]);
+            }
+            auto prefetch = [&](int hbn) {
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int u = 0; u < FO; ++u) fraw[u] = f_load(fit[u], hbn);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hbn, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
+                }
+            };
+            auto stage = [&](int crow0) {
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int u = 0; u < FO; ++u) f_write(fit[u], crow0, fraw[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), crow0, raw[u]);
+                }
+            };
+            (void)NI;
             __syncthreads();                                // tables visible
-#pragma unroll
-            for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), y_begin - R, offr[u], offg[u], offb[u]);
-            // eight stores behind the first prefetch, as in every later trip (k_phosphor_cc: the loop is entered with the same
-            // count of vector memory operations younger than the prefetched bytes as its back edge carries)
+            prefetch(y_begin - R);
+            // eight stores behind the first prefetch, as in every later trip: the loop is entered with the same count of vector
+            // memory operations younger than the prefetched data as its back edge carries
 #pragma unroll
             for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b32(0u, pre_rsrc, 0xFFFFFF00u - 16u * (uint32_t)j, 0, 0);      // out of range: dropped
             CC_PRIO(CC_P_A);
+            int crow0 = 0, c2row0 = NB;
             int hb = y_begin - R;
-            uint32_t cbp0 = 0u, cbp1 = 0u;               // the trip's eight centre bytes, packed (trip 0: rows above the segment, never consumed)
             uint32_t off0 = fin ? (uint32_t)(-2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R of the segment, float f), modulo 2^32 while that row is above it
-            for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b) {
+            for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
+                                            c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
                 // ---- phase 1 ----
                 const int yb = hb - NB - R;                 // first output row of block n-1 (garbage rows in trip 0)
                 const uint32_t slv = scan_load(yb);          // in front of the prefetch below: its wait leaves those loads in flight
                 float v[NB];
+                centre(c2row0, v);                          // issued first: the LDS round trip runs under the V pass
                 {
                     float blur[NB];
                     CC_PRIO(CC_P_VH);
                     v_pass(blur);
                     CC_PRIO(CC_P_A);
 #pragma unroll
-                    for (int j = 0; j < NB; ++j)         // a1 of the centre byte (v_cvt_f32_ubyteN; a2 is in the load's column); ref:611 — only v[] crosses the barrier
-                        v[j] = clip01(a1(((j < 4 ? cbp0 : cbp1) >> (8 * (j & 3))) & 255u) + P.bloom_strength * blur[j]);
+                    for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);      // ref:611 — only v[] crosses the barrier
                 }
                 STAMP(4);
 #if !(CT_EXP & 2)
-                {
-                    float nv[AO][3];
-#pragma unroll
-                    for (int u = 0; u < AO; ++u) { nv[u][0] = a1(raw[u].r); nv[u][1] = a1(raw[u].g); nv[u][2] = a1(raw[u].b); }
-#pragma unroll
-                    for (int u = 0; u < AO; ++u) a_write(min(wave + 3 * u, NA - A3 - 1), nv[u]);
-                }
-#endif
-                // the centre bytes of the NEXT trip's rows (L2 hits: staged a trip ago), requested IN FRONT of the prefetch and of
-                // this trip's stores: vector memory operations complete in order, so a wait for them placed behind either would
-                // also be a wait for the prefetch's HBM round trip / the stores' acknowledgements.  Packed into two registers in the tail.
-                uint32_t cb[NB];
-                centre_load(yb + NB, cb);
-                __builtin_amdgcn_sched_barrier(0);          // ... and the scheduler keeps them in front
-#if !(CT_EXP & 2)
-#pragma unroll
-                for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hb + NB, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
+                stage(crow0);                               // A(n): the data requested one trip ago -> staging tile + ring
+                prefetch(hb + NB);
 #endif
                 STAMP(0);
                 CT_BARRIER();
@@ -374,8 +437,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #else
                 (void)gt_b; (void)slv;
 #endif
-                cbp0 = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
-                cbp1 = cb[4] | (cb[5] << 8) | (cb[6] << 16) | (cb[7] << 24);
                 {
                     uint32_t boff = off0;
 #pragma unroll
@@ -403,11 +464,12 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 const int yb = hb - NB - R;
                 const uint32_t slv = scan_load(yb);
                 float v[NB], blur[NB];
+                centre(c2row0, v);
                 v_pass(blur);
                 __syncthreads();
                 const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) v[j] = clip01(a1(((j < 4 ? cbp0 : cbp1) >> (8 * (j & 3))) & 255u) + P.bloom_strength * blur[j]);
+                for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);
                 triad(v);
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -419,71 +481,97 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 }
             }
         };
-        if (comp) consumer(std::true_type{});
+        if (fast) consumer(std::true_type{});
         else consumer(std::false_type{});
     } else {
         // =============================== HELPER: wave 3 ======================================================================
-        const int xg = x0 + lane;
-        const double cnx2 = P.vig_nx2[min(xg, W - 1)];
-        constexpr int A3R = A3 > 0 ? A3 : 1;
-        uint32_t offr[A3R], offg[A3R], offb[A3R];
-        RawRGB raw[A3R];
+        // lane = pixel column: the float64 vignette gain tile of block n-1 (phase 1), the grain tile of block n (phase 2), and its
+        // share of the A items
+        auto helper = [&](auto fast_c) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            const int xg = x0 + lane;
+            const double cnx2 = P.vig_nx2[min(xg, W - 1)];
+            constexpr int NH = FAST ? (FH > 0 ? FH : 1) : (A3 > 0 ? A3 : 1);
+            FItem fit[FAST ? NH : 1];
+            uint32_t fraw[FAST ? NH : 1];
+            uint32_t offr[FAST ? 1 : NH], offg[FAST ? 1 : NH], offb[FAST ? 1 : NH];
+            RawRGB raw[FAST ? 1 : NH];
+            if constexpr (FAST) {
 #pragma unroll
-        for (int u = 0; u < A3; ++u) a_offsets(NA - A3 + u, offr[u], offg[u], offb[u]);
-        __syncthreads();
+                for (int u = 0; u < FH; ++u) fit[u] = f_setup(3 * FO + u);
+            } else {
 #pragma unroll
-        for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, y_begin - R, offr[u], offg[u], offb[u]);
-        CC_PRIO(CC_P_HELP);
-        int hb = y_begin - R;
-        // a9 vignette gain of the 8 x 64 pixels of output rows yb .. yb + 7: ny^2 of a row is wave-uniform (s_load_dwordx2)
-        const __amdgpu_buffer_rsrc_t ny2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.vig_ny2), 0, H * 8, 0x00020000);
-        auto vig_tile = [&](int yb) {
-            // ny^2 of rows yb .. yb + 7: 8-byte loads at wave-uniform addresses, the offset in the (range-checked) vector operand;
-            // rows outside the frame read 0 (never consumed)
-            const uint32_t vo = (uint32_t)yb * 8u;
-            uint64_t q[NB];
+                for (int u = 0; u < A3; ++u) a_offsets(NA - A3 + u, offr[u], offg[u], offb[u]);
+            }
+            // a short window (small aberration) leaves the last wave-items wholly past its end: skipped (a wave-uniform test)
+            auto live = [&](int u) { return (3 * FO + u) * 64 < NB * ND; };
+            auto prefetch = [&](int hbn) {
+                if constexpr (FAST) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) q[j] = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(ny2_rsrc, vo + 8u * (uint32_t)j, 0, 0));
+                    for (int u = 0; u < FH; ++u) if (live(u)) fraw[u] = f_load(fit[u], hbn);
+                } else {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) gvig[j * TW + lane] = vignette_gain(P, cnx2, __builtin_bit_cast(double, q[j]));
-        };
-        for (int n = 0; n < n_iter; ++n, hb += NB) {
-            // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
+                    for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hbn, offr[u], offg[u], offb[u]);
+                }
+            };
+            auto stage = [&](int crow0) {
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int u = 0; u < FH; ++u) if (live(u)) f_write(fit[u], crow0, fraw[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < A3; ++u) a_write(NA - A3 + u, crow0, raw[u]);
+                }
+            };
+            __syncthreads();
+            prefetch(y_begin - R);
+            CC_PRIO(CC_P_HELP);
+            int crow0 = 0;
+            int hb = y_begin - R;
+            // a9 vignette gain of the 8 x 64 pixels of output rows yb .. yb + 7: ny^2 of a row from 8-byte loads at wave-uniform
+            // addresses, the offset in the (range-checked) vector operand; rows outside the frame read 0 (never consumed)
+            const __amdgpu_buffer_rsrc_t ny2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P.vig_ny2), 0, H * 8, 0x00020000);
+            auto vig_tile = [&](int yb) {
+                const uint32_t vo = (uint32_t)yb * 8u;
+                uint64_t q[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) q[j] = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(ny2_rsrc, vo + 8u * (uint32_t)j, 0, 0));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) gvig[j * TW + lane] = vignette_gain(P, cnx2, __builtin_bit_cast(double, q[j]));
+            };
+            for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB) {
+                // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
 #if !(CT_EXP & 8)
-            vig_tile(hb - NB - R);
+                vig_tile(hb - NB - R);
 #endif
-            STAMP(4);
+                STAMP(4);
 #if !(CT_EXP & 2)
-            {
-                float nv[A3R][3];
-#pragma unroll
-                for (int u = 0; u < A3; ++u) { nv[u][0] = a1(raw[u].r); nv[u][1] = a1(raw[u].g); nv[u][2] = a1(raw[u].b); }
-#pragma unroll
-                for (int u = 0; u < A3; ++u) a_write(NA - A3 + u, nv[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hb + NB, offr[u], offg[u], offb[u]);
+                stage(crow0);
+                prefetch(hb + NB);
 #endif
-            STAMP(0);
-            CT_BARRIER();
-            STAMP(1);
-            // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip) ----
+                STAMP(0);
+                CT_BARRIER();
+                STAMP(1);
+                // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip) ----
 #if !(CT_EXP & 8)
-            float* gw = gn + (n & 1) * NB * TW;
+                float* gw = gn + (n & 1) * NB * TW;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int y = min(max(hb - R + j, 0), H - 1);
-                const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
-                gw[j * TW + lane] = z * P.noise_scale;
-            }
+                for (int j = 0; j < NB; ++j) {
+                    const int y = min(max(hb - R + j, 0), H - 1);
+                    const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
+                    gw[j * TW + lane] = z * P.noise_scale;
+                }
 #endif
-            STAMP(6);
-            STAMP(2);
-            CT_BARRIER();
-            STAMP(3);
-        }
-        vig_tile(hb - NB - R);
-        __syncthreads();
+                STAMP(6);
+                STAMP(2);
+                CT_BARRIER();
+                STAMP(3);
+            }
+            vig_tile(hb - NB - R);
+            __syncthreads();
+        };
+        if (fast) helper(std::true_type{});
+        else helper(std::false_type{});
     }
 #ifdef CRTFX_STAMP
     if (O.dbg && lane == 0) {

@@ -27,11 +27,13 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
             }                                                                                                             \
         }                                                                                                                 \
     } while (0)
-#if RR_R <= 30
-    if (variant == 6) {     // as variant 4 on the composite-table build (k_phosphor_ct; five blocks per CU at radii <= 12)
+#if RR_R <= 12
+    if (variant == 6) {     // as variant 4 on the dword-load / composite-table build (k_phosphor_ct, radii <= 12)
         CRTFX_LAUNCH((k_phosphor_ct<RR_R>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
         return;
     }
+#endif
+#if RR_R <= 30
     if (variant == 4) {     // full-chain gates, pre-warp image out: the column-owner kernel (uint8 frames)
         CRTFX_LAUNCH((k_phosphor_cc<RR_R, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
         return;
