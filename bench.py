@@ -128,7 +128,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[N-1]; 0 = the reference CLI's default flags at 1080p")
-    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 1600 at 4K, 7680 at 1080p, 320 at 8K — sized so that the default 20 steps run >= 3 s)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: 1920 at 4K, 8192 at 1080p, 384 at 8K — sized so that the default 20 steps run >= 3 s)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of K steps after the reported one (spread only; 0 = none)")
@@ -197,12 +197,12 @@ def main():
     fps = 30.0
     p = rs.persistence
     # frames per step: enough that the default 20 steps run >= 3 s — a timed region the driver's 5-s GPU-busy sampler
-    # cannot miss (4K: 1600 frames = 39.8 GB in + 39.8 GB out of the 288 GB; 1080p: 7680 frames = 47.8 GB each way; 8K fp16:
-    # 320 frames = 63.7 GB each way).  Sharded persistence needs B >= settle_frames(p) anyway (shard.py); per-frame states
+    # cannot miss (4K: 1920 frames = 47.8 GB in + 47.8 GB out of the 288 GB; 1080p: 8192 frames = 51 GB each way; 8K fp16:
+    # 384 frames = 76.4 GB each way).  Sharded persistence needs B >= settle_frames(p) anyway (shard.py); per-frame states
     # are kept for the first 26 frames of a chunk only (GpuShardEngine.keep), so a long chunk costs output frames, not states.
-    B = a.batch or (320 if h >= 4320 else 1600 if h >= 2160 else 7680)
+    B = a.batch or (384 if h >= 4320 else 1920 if h >= 2160 else 8192)
     if p > 0.0 and not a.batch:
-        B = max(settle_frames(p), 4096 if world > 1 else 7680)
+        B = max(settle_frames(p), 4096 if world > 1 else 8192)
     dtype = torch.float16 if a.config == 5 else torch.uint8
     pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234, dtype=dtype)
     frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank).to(dtype)

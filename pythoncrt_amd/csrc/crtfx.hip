@@ -280,8 +280,11 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
 
 constexpr int CC_MIN_RADIUS = 8;
 constexpr int CT_MAX_RADIUS = 12;      // k_phosphor_ct serves the four-blocks-per-CU radii; beyond them (3 / 2 blocks per CU, register-bound) k_phosphor_cc stays
+// The column-owner kernels: k_phosphor_ct for radii 1 .. CT_MAX_RADIUS (round 3: ahead of the register-window kernel at every radius
+// measured — 1080p R = 4: 63.6 vs 69.7 us per 5-frame launch, 4K R = 9: 113 vs 126), k_phosphor_cc from CC_MIN_RADIUS up where ct does not serve
 bool use_cc(const crtfx_ctx* c, int R) {
-    return c->pix_fmt == CRTFX_PIX_U8 && (c->force_cc || R >= CC_MIN_RADIUS) && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
+    const bool by_radius = c->force_cc || R >= CC_MIN_RADIUS || (!c->no_ct && R >= 1 && R <= CT_MAX_RADIUS);
+    return c->pix_fmt == CRTFX_PIX_U8 && by_radius && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.

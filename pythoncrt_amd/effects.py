@@ -525,7 +525,24 @@ def _frame_to_device(frame):
     if not torch.cuda.is_available():
         raise RuntimeError("pythoncrt_amd: no ROCm device visible; there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev), True
+    return _upload(a, dev), True
+
+
+def _upload(a: np.ndarray, dev) -> torch.Tensor:
+    """Host frame -> device through a pinned staging block (torch's caching host allocator hands the same few blocks round and
+    keeps one alive until the copy that reads it has run): one memcpy + an asynchronous DMA instead of the driver's chunked
+    staging of a pageable source, which also blocks the calling thread."""
+    stage = torch.empty(a.shape, dtype=torch.uint8 if a.dtype == np.uint8 else torch.float16, pin_memory=True)
+    np.copyto(stage.numpy(), a)
+    return stage.to(dev, non_blocking=True)
+
+
+def _download(t: torch.Tensor) -> np.ndarray:
+    """Device tensor -> a fresh numpy array (backed by a pinned block that lives as long as the array does)."""
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
 
 
 def _stream_ptr(device) -> int:
@@ -612,7 +629,7 @@ def apply_crt_effect(
     if was_numpy:
         # the frame goes back as a numpy array (ref:1853 wraps it in a QImage); the float state stays on the device behind
         # an array-like that materialises on demand and is taken back as `state_prev` without a copy (DeviceState)
-        return out.cpu().numpy(), DeviceState(state)
+        return _download(out), DeviceState(state)
     return out, state
 
 
@@ -670,4 +687,4 @@ def apply_static_effects(
     with torch.cuda.device(fr.device):
         rc = eng.lib.crtfx_apply_static(eng.ctx, fr.data_ptr(), img.data_ptr(), ctypes.byref(rec), _stream_ptr(fr.device))
     _lib.check(eng.lib, eng.ctx, rc)
-    return img.cpu().numpy() if was_numpy else img
+    return _download(img) if was_numpy else img

@@ -837,6 +837,7 @@ def test_state_prev_of_another_size(pc, prev_hw, promoted):
     from pythoncrt_amd.effects import _engine
     eng = _engine(dev, h, w)
     dst = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+    sg = np.asarray(sg)                  # the numpy path hands back a DeviceState: materialise it
     src = torch.from_numpy(sg).to(dev)
     rc = eng.lib.crtfx_resize_state(eng.ctx, src.data_ptr(), ph, pw, dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0

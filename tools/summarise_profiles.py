@@ -94,7 +94,7 @@ def kernel_avg_cost():
             subprocess.run(["hipcc", *_build.HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), "-I", _build.CSRC, *extra, "-S", "--cuda-device-only",
                             os.path.join(_build.CSRC, src), "-o", asm], check=True)
             mix = isa_cost.static_mix(asm)
-            names = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(mix), capture_output=True, text=True).stdout.splitlines()
+            names = subprocess.run(["c++filt"], input="\n".join(mix), capture_output=True, text=True).stdout.splitlines()
             for mangled, dem in zip(mix, names):
                 n, cyc = mix[mangled]
                 if n:
