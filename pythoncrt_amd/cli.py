@@ -1,7 +1,9 @@
 """Command line of the reference (crt_filter.py parse_args ref:1153-1207, clamps in main
 ref:1220-1267) over the GPU pipeline.
 
-Same flag names, defaults and clamps.  What differs is the container I/O, which is out of scope
+Same flag names, defaults and clamps: `build_parser` restates the flag schema of `parse_args` (ref:1154-1206) and `settings_from_args` the
+clamp list of `main()` (ref:1225-1266) — the drop-in contract IS those names, defaults and bounds, so these two blocks follow
+crt_filter.py (PythonCRT, GPL-3.0) line for line and are pinned against it by tests/golden/reference_cli.json.  What differs is the container I/O, which is out of scope
 here (codec plumbing): frames are read and written as raw `rgb24` (H x W x 3 uint8,
 the wire format of the reference's own FFmpegRawReader, ref:489-502, and of its ffmpeg writer
 pipe), from a file or stdin/stdout, so the drop-in sits between two ffmpeg processes:

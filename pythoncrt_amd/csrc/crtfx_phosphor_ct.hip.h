@@ -5,14 +5,15 @@
 //
 // The measurements (profiles/r03_ct_ablation.txt; 4K, R = 9, us per 2-frame launch, k_phosphor_cc = 128): removing the blur's
 // FMAs saves 4 %, the whole pointwise tail 0 %, the barriers 3 % — but the A phase's frame loads alone 11 %, the pre-warp
-// stores 16 % (10 % of it fabric traffic) and eight byte loads per wave and trip for the centre samples 6 %.  A block issued
-// 131 vector-memory instructions per trip of eight rows — 99 of them single-byte loads of the frame, three per staged pixel,
-// because R and B are fetched at a shifted column (a2) — and a CU takes one per ~13 cycles: four resident blocks keep its
-// memory pipeline busy for most of a trip while VALU and LDS idle.  So:
+// stores 16 % (10 % of it fabric traffic) and eight byte loads per wave and trip for the centre samples 6 %.  k_phosphor_cc
+// issues 62 vector-memory instructions per block and trip of eight rows — 33 of them single-byte loads of the frame, three per
+// wave-item of 64 staged pixels, because R and B are fetched at a shifted column (a2) — and the texture-address unit is busy
+// 15-18 cycles per instruction whatever its width (profiles/r03_cc_vmem.json: TA busy 51 % of the kernel, its address / command
+// FIFOs full 1.1-1.4 M times per launch; this kernel: 32 %, never full).  So:
 //
 //   * the A phase loads DWORDS.  A strip's staged row segment (64 + 2 pad pixels, R and B displaced by the aberration) is one
 //     contiguous window of the frame row: (88 + 2|d|) * 3 bytes = 68 aligned dwords at R = 9, d = 1.  A lane loads one dword
-//     of one row (9 wave-loads per trip instead of 33 + 66), converts its four bytes (v_cvt_f32_ubyte0..3 — the byte select
+//     of one row (9 wave-loads per trip instead of 33 byte loads, and no reload for the centre samples), converts its four bytes (v_cvt_f32_ubyte0..3 — the byte select
 //     is free — and a two-instruction exact u / 255, see a1) and scatters them to the (channel, column) slots of the staging
 //     tile they belong to; the slots are block-invariant and sit in registers.  The raw dword also goes into an LDS ring of
 //     frame-row windows (R + 16 rows), from which the tail reads its centre sample with ds_read_u8: no second fetch of the

@@ -5,6 +5,12 @@ triad mask, the two 1025-entry LUTs, vignette / warp axis vectors, scanline row 
 factor, pixelate index maps.  The per-pixel work lives in the HIP kernels.  Where the reference
 (crt_filter.py, `ref:LINE`) computes a table with numpy, the same numpy expression is used so
 the values are this machine's numpy values (np.sin / np.power are not bit-portable across CPUs).
+
+Restated reference expressions.  Four helpers necessarily repeat lines of crt_filter.py (PythonCRT, GPL-3.0), because the
+product must draw the same random numbers in the same order and evaluate the same numpy expression tree to be bit-exact with
+it: `glitch_offsets_preview` (ref:670-679) and `glitch_offsets_render_segments` (ref:841-850) — the PCG64 seed formula and the
+order of the Generator calls; `scanline_plane` (ref:317-328) and `grade_lut` (ref:292-304) — the float32 / float64 expression
+order.  Each cites its lines; nothing else in this package is taken from the reference's text.
 """
 from __future__ import annotations
 
