@@ -47,10 +47,15 @@ namespace crtfx {
 // what that part costs at full occupancy.  1 blur FMAs, 2 the A phase, 4 the pre-warp stores, 8 the helper wave's tiles, 16 the
 // tail behind img + s * blur, 32 the loop's barriers, 128 the A phase's frame loads only (conversion + staging writes stay),
 // 256 the stores go to a 64 KB window of the scratch image (same instructions, no fabric traffic), 1024 every strip takes the
-// byte-wise A phase and the two-gather triad (the slow path).
+// byte-wise A phase and the two-gather triad (the slow path), 2048 the vignette and grain tiles alias the ring (8 KB less LDS: what would a
+// fifth resident block buy?).
 #ifndef CT_EXP
 #define CT_EXP 0
 #endif
+#ifndef CT_NLUT
+#define CT_NLUT 0         // A/B: a1 (u / 255.0 of a stored byte) from a 256-entry LDS table — one shift + one gather instead of convert + multiply + fma:
+#endif                    // 8 % fewer VALU instructions, 32 % more LDS operations, 3 % SLOWER (profiles/r03_ct_ablation.txt): VALU and LDS are co-bound
+
 #if CT_EXP && !defined(CRTFX_TIMING_EXPERIMENT)
 #error "CT_EXP builds write wrong frames: timing experiments only (-DCRTFX_TIMING_EXPERIMENT)"
 #endif
@@ -64,7 +69,7 @@ __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3
 __host__ __device__ constexpr int ct_ring_words(int R) { return rr_cring(R) * (ct_ndmax(R) > TW ? ct_ndmax(R) : TW); }
 // LDS words: staging, one H-row tile, two tables, the ring of frame-row windows, vignette tile (f64), two grain tiles (f32)
 __host__ __device__ constexpr int ct_lds_words(int R) {
-    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + NB * TW * 2 + 2 * NB * TW;
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + (CT_NLUT ? 256 : 0) + ((CT_EXP & 2048) ? 0 : NB * TW * 2 + 2 * NB * TW);
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 12 ? CT_WAVES : (R <= 20 ? 3 : 2); }
 
@@ -99,9 +104,15 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   composite tables T_m0, T_m1 — or lut_g, lut_inv
     constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [CR][RS] dword          frame-row windows (fast path) / packed centre pixels (byte-wise path)
-    constexpr uint32_t GVIG_B = RING_B + ct_ring_words(R) * 4;               // [NB][TW] double         vignette gain tile
+    constexpr uint32_t NLUT_B = RING_B + ct_ring_words(R) * 4;               // [256] float (CT_NLUT)   u / 255.0
+#if CT_EXP & 2048
+    constexpr uint32_t GVIG_B = RING_B;
+    constexpr uint32_t GN_B = RING_B + NB * TW * 8 < RING_B + ct_ring_words(R) * 4 - 2 * NB * TW * 4 ? RING_B + NB * TW * 8 : RING_B;
+#else
+    constexpr uint32_t GVIG_B = NLUT_B + (CT_NLUT ? 1024 : 0);               // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
     static_assert(GN_B + 2 * NB * TW * 4 == (uint32_t)ct_lds_words(R) * 4, "LDS map and ct_lds_words disagree");
+#endif
     static_assert(SWS - SWP >= 4, "the dword A phase parks the bytes it does not stage in the four pad floats behind a staging plane");
     float* stg = smem;
     float* hrow = smem + HROW_B / 4;
@@ -149,6 +160,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const float* t1 = fast ? P.triad_comp + LUT_N : P.lut_inv;
         for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = t0[i]; lut[LUT_STRIDE + i] = t1[i]; }
     }
+#if CT_NLUT
+    if (tid < 256) LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)tid << 2)) = norm_u8((uint32_t)tid);
+#endif
     const float* taps = P.taps;
     // the taps as R + 1 aligned SGPR pairs (tap[2m], tap[2m+1]); see k_phosphor_cc
     unsigned long long tp[R + 1];
@@ -167,7 +181,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     // correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no f / 255 lies that close to a
     // rounding boundary: its bits beyond the mantissa repeat f's own eight; checked with exact rationals on the host, and
     // against k_phosphor_cc's table of IEEE quotients on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
-    auto a1 = [&](uint32_t u) -> float { const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f); };
+    auto a1 = [&](uint32_t u) -> float {
+#if CT_NLUT
+        return LDS_AT(lds_f32_t, NLUT_B + (u << 2));
+#else
+        const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f);
+#endif
+    };
     // -- byte-wise A phase (k_phosphor_cc's): source element offsets of wave-item q for this lane (block-invariant)
     auto a_offsets = [&](int q, uint32_t& o_r, uint32_t& o_g, uint32_t& o_b) {
         const int it = min((q << 6) + lane, NB * SWP - 1);     // lanes past the tile's last item redo it (same loads, same LDS stores)
