@@ -528,6 +528,39 @@ def test_composite_triad_tables(pc, triad, hw, monkeypatch):
     effects._tls.engines = {}
 
 
+@pytest.mark.parametrize("ab", [0, 2, -1, -3, 5, 8, -8])
+@pytest.mark.parametrize("w", [700, 1028])
+def test_ct_frame_row_windows(pc, ab, w, monkeypatch):
+    """k_phosphor_ct's dword A phase reads each strip's staged row segment as ONE window of the frame row, R and B displaced by the
+    aberration (ref:571-577): every shift the CLI admits (-8 .. 8, ref:1230) and none, on frames wide enough for interior strips
+    (window inside the frame) next to edge strips (byte-wise path: BORDER_REPLICATE + wrap), against k_phosphor_cc bit for bit and
+    against the oracle through the render loop (frame 0 bit-exact)."""
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    h = 26
+    dev = torch.device("cuda", torch.cuda.current_device())
+    clip = np.stack([make_frame(h, w, seed=90 + i, kind="noise" if i else "grad") for i in range(2)])
+    rs = RenderSettings(fast_bloom=False, bloom_sigma=3.0, pixel_size=1, persistence=0.5, aberration_px=ab)     # persistence: the chain parks a pre-warp image
+    got = {}
+    for name, opts in (("ct", {"FORCE_CC": 1}), ("cc", {"FORCE_CC": 1, "NO_CT": 1})):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+        effects._tls.engines = {}
+        pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=5)
+        out, st = pipe.run(torch.from_numpy(clip).to(dev), first_index=1)
+        got[name] = (out.cpu().numpy(), st.cpu().numpy())
+        if name == "ct":
+            gpl = _export_planes(pipe, 5, 1, 2, h, w)
+    effects._tls.engines = {}
+    assert np.array_equal(got["ct"][0], got["cc"][0]) and np.array_equal(got["ct"][1], got["cc"][1])
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+                                          "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")}
+    exp, _ = orc.process_frames(list(clip), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                rs.vignette_strength, noise_planes=gpl, first_index=1)
+    assert np.array_equal(got["ct"][0][0], exp[0])
+    d = np.abs(got["ct"][0].astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
 def test_sharded_persistence_pieces_on_gpu():
     """The GPU engine behind shard.ShardedRender: a chunk scanned from a ZERO incoming state and then
     corrected with p^(j+1) * carry reproduces the in-order render of the same frames."""
