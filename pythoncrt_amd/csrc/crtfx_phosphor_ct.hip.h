@@ -52,6 +52,9 @@ namespace crtfx {
 #ifndef CT_EXP
 #define CT_EXP 0
 #endif
+#ifndef CT_A1_PACKED
+#define CT_A1_PACKED 0    // A/B: u / 255 of two bytes at a time with v_pk_mul_f32 + v_pk_fma_f32 (same roundings per byte): 16 VALU instructions
+#endif                    // fewer per consumer wave and trip, no faster (113.6 - 115.4 scalar vs 114.1 - 115.5 packed): packed float32 costs what two scalars cost
 #ifndef CT_NLUT
 #define CT_NLUT 0         // A/B: a1 (u / 255.0 of a stored byte) from a 256-entry LDS table — one shift + one gather instead of convert + multiply + fma:
 #endif                    // 8 % fewer VALU instructions, 32 % more LDS operations, 3 % SLOWER (profiles/r03_ct_ablation.txt): VALU and LDS are co-bound
@@ -66,7 +69,9 @@ namespace crtfx {
 #endif
 // a frame-row window in dwords, at most: (staged pixels + 2 * 8 of aberration) * 3 bytes, + 3 of alignment slack, + 1
 __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3 + 5) / 4 + 1; }
-__host__ __device__ constexpr int ct_ring_words(int R) { return rr_cring(R) * (ct_ndmax(R) > TW ? ct_ndmax(R) : TW); }
+// the centre ring: CT_RING_ROWS rows (a power of two >= R + 2 NB for every radius this kernel serves) of TW dwords
+constexpr int CT_RING_ROWS = 32;
+__host__ __device__ constexpr int ct_ring_words(int R) { return CT_RING_ROWS * TW; }
 // LDS words: staging, one H-row tile, two tables, the ring of frame-row windows, vignette tile (f64), two grain tiles (f32)
 __host__ __device__ constexpr int ct_lds_words(int R) {
     return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + (CT_NLUT ? 256 : 0) + ((CT_EXP & 2048) ? 0 : NB * TW * 2 + 2 * NB * TW);
@@ -95,7 +100,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr int AO = (NA - A3 + 2) / 3;                // ... of each consumer wave (items wave, wave + 3, ...)
     // dword A phase: wave-items of 64 (row, dword) pairs of the NB row windows
     constexpr int NDMAX = ct_ndmax(R);
-    constexpr int RS = NDMAX > TW ? NDMAX : TW;          // ring row stride in dwords (the byte-wise path parks TW packed pixels per row)
+    // centre ring geometry: 32 rows of 256 bytes.  A staged row r sits in ring row (r - (y_begin - R) + RSH) & 31, RSH = R % NB: the eight rows
+    // the tail reads in one trip then start on a multiple of eight and never wrap — ONE address per trip + immediates j * 256 — and the
+    // modulo of the (per-lane) write row is a mask.  A row holds the 64 packed centre pixels (byte-wise path) or the dwords of the frame-row
+    // window that overlap the centre pixels' bytes (at most 62 for |d| <= 8; dword 63 takes the window's other dwords)
+    constexpr int RSH = R % NB;
+    static_assert(CR <= CT_RING_ROWS && (CT_RING_ROWS & (CT_RING_ROWS - 1)) == 0, "the centre ring holds R + 2 NB rows in a power-of-two ring");
+    constexpr uint32_t RING_MASK = (uint32_t)(CT_RING_ROWS * TW * 4 - 1);
     constexpr int NQF = (NB * NDMAX + 63) / 64;
     constexpr int FO = (NQF + 4) / 5;                    // ... of each consumer wave (items wave, wave + 3, ...)
     constexpr int FH = NQF - 3 * FO > 0 ? NQF - 3 * FO : 0;      // ... of the helper wave (the last ones: mostly past a short window's end)
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr uint32_t STG_B = 0;                                            // [NB][3][SWS] float      staging tile
     constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   composite tables T_m0, T_m1 — or lut_g, lut_inv
-    constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [CR][RS] dword          frame-row windows (fast path) / packed centre pixels (byte-wise path)
+    constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [32][TW] dword          centre ring: frame-row window dwords (fast path) / packed centre pixels (byte-wise path)
     constexpr uint32_t NLUT_B = RING_B + ct_ring_words(R) * 4;               // [256] float (CT_NLUT)   u / 255.0
 #if CT_EXP & 2048
     constexpr uint32_t GVIG_B = RING_B;
@@ -188,6 +199,17 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f);
 #endif
     };
+    // two bytes at once: the multiply and the fma as ONE packed instruction each (v_pk_mul_f32, v_pk_fma_f32) — the same two roundings per byte
+    auto a1x2 = [&](uint32_t u0, uint32_t u1, float& o0, float& o1) {
+#if CT_A1_PACKED
+        const f32x2 fu = {(float)u0, (float)u1};
+        const f32x2 lo = fu * f32x2{-0x1.fdfdfep-33f, -0x1.fdfdfep-33f};
+        const f32x2 r = __builtin_elementwise_fma(fu, f32x2{0x1.010102p-8f, 0x1.010102p-8f}, lo);
+        o0 = r[0]; o1 = r[1];
+#else
+        o0 = a1(u0); o1 = a1(u1);
+#endif
+    };
     // -- byte-wise A phase (k_phosphor_cc's): source element offsets of wave-item q for this lane (block-invariant)
     auto a_offsets = [&](int q, uint32_t& o_r, uint32_t& o_g, uint32_t& o_b) {
         const int it = min((q << 6) + lane, NB * SWP - 1);     // lanes past the tile's last item redo it (same loads, same LDS stores)
@@ -207,26 +229,25 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         return load_raw(0, F.in, ro + o_r, ro + o_g, ro + o_b);
 #endif
     };
-    auto a_write = [&](int q, int crow0, RawRGB v) {
+    auto a_write = [&](int q, uint32_t crow0s, RawRGB v) {      // crow0s: byte offset of the ring row of this trip's first staged row, before the shift
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int j = it / SWP, i = it - j * SWP;
-        if (i >= pad && i < pad + TW) {                    // a centre pixel: parked as packed bytes for the tail
-            int cr = crow0 + j;
-            cr = cr >= CR ? cr - CR : cr;
-            LDS_AT(lds_u32_t, RING_B + (uint32_t)((cr * RS + (i - pad)) * 4)) = v.r | (v.g << 8) | (v.b << 16);
-        }
+        if (i >= pad && i < pad + TW)                      // a centre pixel: parked as packed bytes for the tail
+            LDS_AT(lds_u32_t, RING_B + ((crow0s + (uint32_t)(((j + RSH) * TW + (i - pad)) * 4)) & RING_MASK)) = v.r | (v.g << 8) | (v.b << 16);
         float* sp = stg + (j * 3) * SWS + i;
         sp[0] = a1(v.r); sp[SWS] = a1(v.g); sp[2 * SWS] = a1(v.b);
     };
     // -- dword A phase: item = (row j, dword k of the row window); block-invariant per lane: the dword's byte offset in a frame row,
     // its row, and the staging slots of its four bytes (a byte that belongs to no staged sample goes to a pad float behind its plane)
-    struct FItem { uint32_t ld, j, s[4]; };
+    struct FItem { uint32_t ld, j, s[4], rq; };       // rq: (row j + RSH) * 256 + 4 * (its dword of the ring row)
+    const int kc_lo = (int)(((uint32_t)(x0 - aab) * 3u - a_lo) >> 2), kc_hi = (int)(((uint32_t)(x0 + TW - 1 + aab) * 3u + 2u - a_lo) >> 2);      // window dwords holding centre bytes
     auto f_setup = [&](int q) -> FItem {
         FItem it;
         const int idx = min((q << 6) + lane, NB * ND - 1);      // items past the window's end redo the last one
         const int j = idx / ND, k = idx - j * ND;
         it.ld = a_lo + 4u * (uint32_t)k;
         it.j = (uint32_t)j;
+        it.rq = (uint32_t)((j + RSH) * TW * 4) + 4u * (uint32_t)((k >= kc_lo && k <= kc_hi) ? k - kc_lo : TW - 1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = (int)it.ld + e;                  // byte of the frame row
@@ -245,14 +266,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         return *reinterpret_cast<const uint32_t*>(F.in + ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));
 #endif
     };
-    auto f_write = [&](const FItem& it, int crow0, uint32_t d) {
-        int cr = crow0 + (int)it.j;
-        cr = cr >= CR ? cr - CR : cr;
-        LDS_AT(lds_u32_t, RING_B + (uint32_t)__umul24((uint32_t)cr, (uint32_t)(RS * 4)) + (it.ld - a_lo)) = d;      // the raw window dword
-        LDS_AT(lds_f32_t, it.s[0]) = a1(d & 255u);
-        LDS_AT(lds_f32_t, it.s[1]) = a1((d >> 8) & 255u);
-        LDS_AT(lds_f32_t, it.s[2]) = a1((d >> 16) & 255u);
-        LDS_AT(lds_f32_t, it.s[3]) = a1(d >> 24);
+    auto f_write = [&](const FItem& it, uint32_t crow0s, uint32_t d) {
+        LDS_AT(lds_u32_t, RING_B + ((crow0s + it.rq) & RING_MASK)) = d;      // the raw window dword
+        float o[4];
+        a1x2(d & 255u, (d >> 8) & 255u, o[0], o[1]);
+        a1x2((d >> 16) & 255u, d >> 24, o[2], o[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) LDS_AT(lds_f32_t, it.s[e]) = o[e];
     };
     // H pass of the staging tile by a consumer wave (k_phosphor_cc's: 8 adjacent outputs per lane, lanes mapped through the
     // hardware's 16-lane ds_read_b128 groups; taps left to right, fused — the oracle's RowFilter order)
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             const __amdgpu_buffer_rsrc_t scan_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F.scan_row), 0, H * 4, 0x00020000);
             // this float's centre byte inside a ring row: FAST — its byte of the frame-row window (a2: R from column x - d, B from
             // x + d; the window is inside the frame, no wrap); else byte fch of packed pixel fcol
-            const uint32_t cpl = FAST ? (uint32_t)((x0 + fcol + (fch == 0 ? -P.ab : (fch == 2 ? P.ab : 0))) * 3 + fch) - a_lo
+            const uint32_t cpl = FAST ? (uint32_t)((x0 + fcol + (fch == 0 ? -P.ab : (fch == 2 ? P.ab : 0))) * 3 + fch) - a_lo - 4u * (uint32_t)kc_lo
                                       : (uint32_t)(fcol * 4 + fch);
             f32x2 win2[L / 2];
 #pragma unroll
@@ -347,13 +367,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 for (int i = 0; i < R; ++i) win2[i] = win2[i + NB / 2];
             };
             // a1 of the centre samples of output rows c2row0 .. + 7 of the ring (a2 is in the byte's column)
-            auto centre = [&](int c2row0, float (&v)[NB]) {
+            auto centre = [&](uint32_t c2row0s, float (&v)[NB]) {      // c2row0s: byte offset of the ring row of output row yb (a multiple of 8 rows: no wrap inside)
+                uint32_t cb[NB];
+                const uint32_t cbase = c2row0s + cpl;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    int cr = c2row0 + j;
-                    cr = cr >= CR ? cr - CR : cr;
-                    v[j] = a1((uint32_t)LDS_AT(lds_u8_t, RING_B + (uint32_t)(cr * RS * 4) + cpl));
-                }
+                for (int j = 0; j < NB; ++j) cb[j] = (uint32_t)LDS_AT(lds_u8_t, RING_B + (uint32_t)(j * TW * 4) + cbase);
+#pragma unroll
+                for (int j = 0; j < NB; j += 2) a1x2(cb[j], cb[j + 1], v[j], v[j + 1]);
             };
             // the scanline gains of rows yb .. yb + 7: lane l asks for row yb + (l & 7) — ONE load per wave and trip, one VGPR across
             // the barrier — and the tail reads row j's gain out of lane j (v_readlane: an SGPR operand of its multiply).  The offset
@@ -393,7 +413,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     for (int u = 0; u < AO; ++u) raw[u] = a_load(min(wave + 3 * u, NA - A3 - 1), hbn, offr[u], offg[u], offb[u]);   // past the last block: clamped rows, never consumed
                 }
             };
-            auto stage = [&](int crow0) {
+            auto stage = [&](uint32_t crow0) {
                 if constexpr (FAST) {
 #pragma unroll
                     for (int u = 0; u < FO; ++u) f_write(fit[u], crow0, fraw[u]);
@@ -410,11 +430,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
             for (int j = 0; j < NB; ++j) __builtin_amdgcn_raw_buffer_store_b32(0u, pre_rsrc, 0xFFFFFF00u - 16u * (uint32_t)j, 0, 0);      // out of range: dropped
             CC_PRIO(CC_P_A);
-            int crow0 = 0, c2row0 = NB;
+            // ring rows as byte offsets: trip n stages rows hb + j into ring rows (n * NB + j + RSH) & 31 and reads the centre rows of
+            // output rows yb + j = hb - NB - R + j from ring rows (n * NB - NB - (R - RSH) + j) & 31
+            uint32_t crow0 = 0u, c2row0 = (uint32_t)((-NB - (R - RSH)) * TW * 4) & RING_MASK;
             int hb = y_begin - R;
             uint32_t off0 = fin ? (uint32_t)(-2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R of the segment, float f), modulo 2^32 while that row is above it
-            for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB,
-                                            c2row0 = c2row0 + NB >= CR ? c2row0 + NB - CR : c2row0 + NB) {
+            for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = (crow0 + NB * TW * 4) & RING_MASK,
+                                            c2row0 = (c2row0 + NB * TW * 4) & RING_MASK) {
                 // ---- phase 1 ----
                 const int yb = hb - NB - R;                 // first output row of block n-1 (garbage rows in trip 0)
                 const uint32_t slv = scan_load(yb);          // in front of the prefetch below: its wait leaves those loads in flight
@@ -535,7 +557,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     for (int u = 0; u < A3; ++u) raw[u] = a_load(NA - A3 + u, hbn, offr[u], offg[u], offb[u]);
                 }
             };
-            auto stage = [&](int crow0) {
+            auto stage = [&](uint32_t crow0) {
                 if constexpr (FAST) {
 #pragma unroll
                     for (int u = 0; u < FH; ++u) if (live(u)) f_write(fit[u], crow0, fraw[u]);
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             __syncthreads();
             prefetch(y_begin - R);
             CC_PRIO(CC_P_HELP);
-            int crow0 = 0;
+            uint32_t crow0 = 0u;
             int hb = y_begin - R;
             // a9 vignette gain of the 8 x 64 pixels of output rows yb .. yb + 7: ny^2 of a row from 8-byte loads at wave-uniform
             // addresses, the offset in the (range-checked) vector operand; rows outside the frame read 0 (never consumed)
@@ -560,7 +582,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
                 for (int j = 0; j < NB; ++j) gvig[j * TW + lane] = vignette_gain(P, cnx2, __builtin_bit_cast(double, q[j]));
             };
-            for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = crow0 + NB >= CR ? crow0 + NB - CR : crow0 + NB) {
+            for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = (crow0 + NB * TW * 4) & RING_MASK) {
                 // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
 #if !(CT_EXP & 8)
                 vig_tile(hb - NB - R);
