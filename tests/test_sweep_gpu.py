@@ -98,3 +98,54 @@ def test_extreme_aspect_frames(hw):
                                 rs.vignette_strength)
     d = np.abs(out.cpu().numpy().astype(np.int16) - np.stack(exp).astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 2e-3, (hw, int(d.max()), float((d != 0).mean()))
+
+
+CT_SIZES = [(40, 704), (26, 1028), (9, 512), (64, 322), (17, 960), (130, 260), (8, 4096), (33, 641)]
+
+
+@pytest.mark.parametrize("case", range(32))
+def test_random_full_chain_on_the_headline_kernel(case):
+    """The gate set of BASELINE configs 2-5 (scanlines + triad LUTs + Gaussian bloom + vignette + grain, warp or persistence behind
+    it) is what k_phosphor_ct serves: 32 seeded draws of everything that varies INSIDE that gate set — bloom radius 1..12, strengths,
+    triad strength / softness (two-valued, three-valued and unsoftened masks), aberration -8..8, scanline period / phase, frame sizes with
+    interior strips, edge strips, partial last strips and widths that are not a multiple of four — through the render loop against the
+    oracle's in-order render.  No warp: frame 0 bit-exact (it is the quantised pre-warp image) and the blended frames <= 1 LSB."""
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    rng = np.random.default_rng(7000 + case)
+    pick = lambda *a: a[int(rng.integers(len(a)))]
+    h, w = CT_SIZES[case % len(CT_SIZES)]
+    warp = pick(0.0, 0.0, 0.15)
+    rs = RenderSettings(
+        scanline_strength=pick(0.3, 0.6, 1.0), triad_strength=pick(0.2, 0.35, 0.5, 1.0), triad_gamma=pick(2.2, 1.8, 0.6), triad_preserve_luma=False,
+        triad_softness=pick(0.0, 0.5, 1.0, 2.0), aberration_px=int(rng.integers(-8, 9)), bloom_sigma=pick(0.2, 0.5, 1.0, 1.2, 2.0, 2.7, 3.0, 3.7, 4.0),
+        bloom_strength=pick(0.1, 0.25, 0.9), bloom_threshold=0.0, noise_strength=pick(0.5, 1.5, 6.0), vignette_strength=pick(0.1, 0.25, 1.0),
+        persistence=(pick(0.2, 0.5) if warp == 0.0 else pick(0.0, 0.5)), scanline_speed_px_s=pick(30.0, -12.5, 7.0), scanline_period_px=pick(2.0, 3.7),
+        fast_bloom=False, pixel_size=1, warp_strength=warp)
+    n, first, fps, seed = 4, int(rng.integers(0, 40)), 25.0, int(rng.integers(1 << 40))
+    kind = rng.integers(3)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    if kind == 1:
+        frames[:] = (np.arange(w, dtype=np.int64)[None, None, :, None] * 7 + np.arange(h)[None, :, None, None] * 3 + np.arange(3)[None, None, None, :] * 50) % 256
+    elif kind == 2:
+        frames[:, :, : w // 2] = 255          # saturated half: bloom clips, LUT index 1024
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    planes = []
+    for i in range(n):
+        p = torch.empty((h, w), dtype=torch.float32, device=dev)
+        assert pipe.lib.crtfx_noise_plane(pipe.engine.ctx, seed, first + i, p.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        planes.append(p.cpu().numpy())
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+                                          "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")}
+    exp, exp_state = orc.process_frames(list(frames), params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                        rs.vignette_strength, noise_planes=planes, first_index=first)
+    got = out.cpu().numpy()
+    if warp == 0.0:
+        assert np.array_equal(got[0], exp[0]), (case, rs)
+    d = np.abs(got.astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() <= 2e-3, (case, rs, int(d.max()), float((d != 0).mean()))
+    if rs.persistence > 0.0:
+        assert np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6
