@@ -108,7 +108,7 @@ valu = sum(d.get("SQ_INSTS_VALU", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.item
 valu_w = sum(d.get("SQ_INSTS_VALU", 0) * cost_of(k) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
 lds_act = sum(d.get("SQ_LDS_IDX_ACTIVE", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
 lds_bc = sum(d.get("SQ_LDS_BANK_CONFLICT", 0) / fpl.get(cls(k), 1.0) for k, d in pmc.items())
-domk = max(pmc, key=lambda k: pmc[k].get("SQ_WAVE_CYCLES", 0)) if pmc else None
+domk = max(pmc, key=lambda k: (pmc[k].get("GRBM_GUI_ACTIVE", 0), pmc[k].get("SQ_WAVE_CYCLES", 0))) if pmc else None      # the kernel that runs longest per launch
 dom_wave = dom_lds = None
 if domk:
     d = pmc[domk]
