@@ -13,10 +13,11 @@
 //
 //   * the A phase loads DWORDS.  A strip's staged row segment (64 + 2 pad pixels, R and B displaced by the aberration) is one
 //     contiguous window of the frame row: (88 + 2|d|) * 3 bytes = 68 aligned dwords at R = 9, d = 1.  A lane loads one dword
-//     of one row (9 wave-loads per trip instead of 33 byte loads, and no reload for the centre samples), converts its four bytes (v_cvt_f32_ubyte0..3 — the byte select
-//     is free — and a two-instruction exact u / 255, see a1) and scatters them to the (channel, column) slots of the staging
-//     tile they belong to; the slots are block-invariant and sit in registers.  The raw dword also goes into an LDS ring of
-//     frame-row windows (R + 16 rows), from which the tail reads its centre sample with ds_read_u8: no second fetch of the
+//     of one row (9 wave-loads per trip instead of 33 byte loads), converts its four bytes (v_cvt_f32_ubyte0..3 — the byte
+//     select is free — and a two-instruction exact u / 255, see a1) and scatters them to the (channel, column) slots of the
+//     staging tile they belong to; the slots are block-invariant and sit in registers.  The raw dword also goes into an LDS
+//     ring of row windows (32 rows of 256 bytes: the window dwords that overlap the centre pixels), from which the tail
+//     reads its centre sample with ds_read_u8 — eight rows per trip at one address + immediates: no second fetch of the
 //     frame, no byte loads at all.  Rows need W % 4 == 0 (dword-aligned rows) and a window inside the frame: the first and last
 //     strip(s), where BORDER_REPLICATE and the aberration's wrap bend the window, run k_phosphor_cc's byte-wise A phase
 //     (a second copy of the loop, chosen per block; blocks of both kinds share a launch).
@@ -47,8 +48,8 @@ namespace crtfx {
 // what that part costs at full occupancy.  1 blur FMAs, 2 the A phase, 4 the pre-warp stores, 8 the helper wave's tiles, 16 the
 // tail behind img + s * blur, 32 the loop's barriers, 128 the A phase's frame loads only (conversion + staging writes stay),
 // 256 the stores go to a 64 KB window of the scratch image (same instructions, no fabric traffic), 1024 every strip takes the
-// byte-wise A phase and the two-gather triad (the slow path), 2048 the vignette and grain tiles alias the ring (8 KB less LDS: what would a
-// fifth resident block buy?).
+// byte-wise A phase and the two-gather triad (the slow path), 2048 the vignette and grain tiles alias the ring (8 KB less LDS:
+// what would a fifth resident block buy?).  Results: profiles/r03_ct_ablation.txt.
 #ifndef CT_EXP
 #define CT_EXP 0
 #endif
@@ -72,7 +73,7 @@ __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3
 // the centre ring: CT_RING_ROWS rows (a power of two >= R + 2 NB for every radius this kernel serves) of TW dwords
 constexpr int CT_RING_ROWS = 32;
 __host__ __device__ constexpr int ct_ring_words(int R) { return CT_RING_ROWS * TW; }
-// LDS words: staging, one H-row tile, two tables, the ring of frame-row windows, vignette tile (f64), two grain tiles (f32)
+// LDS words: staging, one H-row tile, two tables, the centre ring, vignette tile (f64), two grain tiles (f32): 38.8 KB at R = 9
 __host__ __device__ constexpr int ct_lds_words(int R) {
     return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + (CT_NLUT ? 256 : 0) + ((CT_EXP & 2048) ? 0 : NB * TW * 2 + 2 * NB * TW);
 }
