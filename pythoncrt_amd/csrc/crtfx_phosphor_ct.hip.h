@@ -56,6 +56,9 @@ namespace crtfx {
 #ifndef CT_A1_PACKED
 #define CT_A1_PACKED 0    // A/B: u / 255 of two bytes at a time with v_pk_mul_f32 + v_pk_fma_f32 (same roundings per byte): 16 VALU instructions
 #endif                    // fewer per consumer wave and trip, no faster (113.6 - 115.4 scalar vs 114.1 - 115.5 packed): packed float32 costs what two scalars cost
+#ifndef CT_WARM_SKIP
+#define CT_WARM_SKIP 1    // skip the taps and the tail of the trips whose output rows all lie above the block's segment (window fill only)
+#endif
 #ifndef CT_NLUT
 #define CT_NLUT 0         // A/B: a1 (u / 255.0 of a stored byte) from a 256-entry LDS table — one shift + one gather instead of convert + multiply + fma:
 #endif                    // 8 % fewer VALU instructions, 32 % more LDS operations, 3 % SLOWER (profiles/r03_ct_ablation.txt): VALU and LDS are co-bound
@@ -341,13 +344,14 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
             // C1: append the eight H rows of the tile, form output rows j (x) and j + 1 (y) of each pair from window elements
             // i = j .. j + 2R + 1 oldest first, shift the window down by NB
-            auto v_pass = [&](float (&blur)[NB]) {
+            auto v_pass = [&](float (&blur)[NB], bool warm) {
                 const float* hcol = hrow + f;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) win2[(2 * R + j) >> 1][j & 1] = hcol[j * CC_HROW];
                 f32x2 acc[NB / 2];
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) acc[jp] = f32x2{0.0f, 0.0f};
+                if (!warm) {
 #if CT_EXP & 1
 #pragma unroll
                 for (int i = 0; i < L; ++i) { if (i & 1) acc[(i >> 1) & 3].y += win2[i >> 1][1]; else acc[(i >> 1) & 3].x += win2[i >> 1][0]; }
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                         else if (t == 2 * R + 1) acc[jp].y = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].y);       // tap[2R] == tap[0]
                     }
 #endif
+                }
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) { blur[2 * jp] = acc[jp].x; blur[2 * jp + 1] = acc[jp].y; }
 #pragma unroll
@@ -441,15 +446,23 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 // ---- phase 1 ----
                 const int yb = hb - NB - R;                 // first output row of block n-1 (garbage rows in trip 0)
                 const uint32_t slv = scan_load(yb);          // in front of the prefetch below: its wait leaves those loads in flight
+                // the first trips of a block only fill the row window: all their output rows lie above the segment (their stores
+                // are dropped by the buffer's range check), so the taps and the tail are skipped — a wave-uniform test
+                const bool warm = CT_WARM_SKIP && yb + NB <= y_begin;
                 float v[NB];
-                centre(c2row0, v);                          // issued first: the LDS round trip runs under the V pass
+                if (!warm) centre(c2row0, v);               // issued first: the LDS round trip runs under the V pass
                 {
                     float blur[NB];
                     CC_PRIO(CC_P_VH);
-                    v_pass(blur);
+                    v_pass(blur, warm);
                     CC_PRIO(CC_P_A);
+                    if (!warm) {
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);      // ref:611 — only v[] crosses the barrier
+                        for (int j = 0; j < NB; ++j) v[j] = clip01(v[j] + P.bloom_strength * blur[j]);      // ref:611 — only v[] crosses the barrier
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) v[j] = 0.0f;
+                    }
                 }
                 STAMP(4);
 #if !(CT_EXP & 2)
@@ -463,20 +476,22 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 CC_PRIO(CC_P_C2);
                 const uint32_t gt_b = GN_B + (uint32_t)(((n & 1) ^ 1) * NB * TW * 4) + gcol4;
 #if !(CT_EXP & 16)
-                float gnv[NB];
-                double gv[NB];
+                if (!warm) {
+                    float gnv[NB];
+                    double gv[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    gv[j] = LDS_AT(lds_f64_t, GVIG_B + (uint32_t)(j * TW * 8) + gcol8);
-                    gnv[j] = LDS_AT(lds_f32_t, gt_b + (uint32_t)(j * TW * 4));
-                }
-                triad(v);
+                    for (int j = 0; j < NB; ++j) {
+                        gv[j] = LDS_AT(lds_f64_t, GVIG_B + (uint32_t)(j * TW * 8) + gcol8);
+                        gnv[j] = LDS_AT(lds_f32_t, gt_b + (uint32_t)(j * TW * 4));
+                    }
+                    triad(v);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const float r = clip01(v[j] * __uint_as_float(__builtin_amdgcn_readlane(slv, j)));   // ref:617-624
-                    double d = (double)r * gv[j];                                                       // ref:626-628 (gain in [0,1]: no clip)
-                    d = clip01(d + (double)gnv[j]);                                                     // ref:646-647
-                    v[j] = (float)d;
+                    for (int j = 0; j < NB; ++j) {
+                        const float r = clip01(v[j] * __uint_as_float(__builtin_amdgcn_readlane(slv, j)));   // ref:617-624
+                        double d = (double)r * gv[j];                                                       // ref:626-628 (gain in [0,1]: no clip)
+                        d = clip01(d + (double)gnv[j]);                                                     // ref:646-647
+                        v[j] = (float)d;
+                    }
                 }
 #else
                 (void)gt_b; (void)slv;
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 const uint32_t slv = scan_load(yb);
                 float v[NB], blur[NB];
                 centre(c2row0, v);
-                v_pass(blur);
+                v_pass(blur, false);
                 __syncthreads();
                 const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
 #pragma unroll
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = (crow0 + NB * TW * 4) & RING_MASK) {
                 // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
 #if !(CT_EXP & 8)
-                vig_tile(hb - NB - R);
+                if (!(CT_WARM_SKIP && hb - R <= y_begin)) vig_tile(hb - NB - R);        // rows above the segment: never consumed
 #endif
                 STAMP(4);
 #if !(CT_EXP & 2)
@@ -599,11 +614,13 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip) ----
 #if !(CT_EXP & 8)
                 float* gw = gn + (n & 1) * NB * TW;
+                if (!(CT_WARM_SKIP && hb - R + NB <= y_begin)) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int y = min(max(hb - R + j, 0), H - 1);
-                    const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
-                    gw[j * TW + lane] = z * P.noise_scale;
+                    for (int j = 0; j < NB; ++j) {
+                        const int y = min(max(hb - R + j, 0), H - 1);
+                        const float z = grain_normal(F.key0, F.key1, (uint32_t)y * (uint32_t)W + (uint32_t)xg);
+                        gw[j * TW + lane] = z * P.noise_scale;
+                    }
                 }
 #endif
                 STAMP(6);
