@@ -224,7 +224,7 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   FORCE_CC             ... take k_phosphor_cc for every radius and both pixel formats (it is the default only where it is faster)
  *   NO_CT                ... stay on k_phosphor_cc instead of its composite-table build k_phosphor_ct (A/B)
  *   GROUP, SEG_ROWS      frames per grid (1..8 = CRTFX_MAX_GROUP) / rows per block of the register-window kernels; 0 = the planner's choice
- *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4)
+ *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4; 0 = the launcher's choice: 4, or 2 with a persistence chain)
  *   POINT_TILES          rows per k_point block (1..16; 0 = default)
  *   OVERLAP              run k_warp(n) on a side stream beside k_phosphor(n+1) (measured slower; kept for A/B)
  *   SPLIT_FROM           Gaussian-bloom radii >= this run the split path (blur kernels of any radius + the pointwise chain)

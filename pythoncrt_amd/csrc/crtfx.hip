@@ -58,7 +58,7 @@ struct crtfx_ctx {
     int seg_rows = 0;                // rows per k_phosphor block
     unsigned long long* dbg = nullptr;   // -DCRTFX_STAMP builds only: crtfx_debug_buffer hands in a device buffer
     bool force_generic = false;      // CRTFX_OPT_FORCE_GENERIC: always take the LDS-ring kernel (tests)
-    int warp_rows = 2;               // CRTFX_OPT_WARP_ROWS = 1|2|4: output rows per k_warp_lean thread
+    int warp_rows = 0;               // CRTFX_OPT_WARP_ROWS = 0 (the launcher's choice) |1|2|4: output rows per k_warp_lean thread
     int point_tiles = 0;             // CRTFX_OPT_POINT_TILES = n: rows (wavefronts) per k_point block, 1..16 (0 = default)
     bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
     bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
@@ -347,21 +347,24 @@ void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3
     else { if (render) launch_point_lean2<SF_FAST, CRTFX_BLEND_RENDER>(c, grid, block, s, e0, e1, kf, ko); else launch_point_lean2<SF_FAST, CRTFX_BLEND_NONE>(c, grid, block, s, e0, e1, kf, ko); }
 }
 
-template <bool PROMOTE, int BLEND>
-void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const int rows = c->warp_rows;      // output rows per thread
-    grid.y = (c->H + 4 * rows - 1) / (4 * rows);
+template <bool PROMOTE, int BLEND, int PIX>
+void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    // frames without a persistence chain: 4 rows per thread in a 128 x 8 tile; with one (the float32 state of every row in registers
+    // as well): 2 rows, 64 x 8 — 1080p, 5 frames per launch: 40.0 against 46.7 us with 4 rows (profiles/r03_ct_ablation.txt, E)
+    constexpr int WX = BLEND == CRTFX_BLEND_RENDER ? 1 : 2;
+    const int rows = c->warp_rows ? c->warp_rows : (BLEND == CRTFX_BLEND_RENDER ? 2 : 4);      // output rows per thread
+    grid.x = (grid.x + WX - 1) / WX;
+    grid.y = (c->H + (4 / WX) * rows - 1) / ((4 / WX) * rows);
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
-    if (c->pix_fmt == CRTFX_PIX_F16) {
-        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_F16, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-    } else {
-        if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 4>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-        else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 2>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-        else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, CRTFX_PIX_U8, 1>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-    }
+    if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+    else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+}
+template <bool PROMOTE, int BLEND>
+void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (c->pix_fmt == CRTFX_PIX_F16) launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_F16>(c, wg, grid, nseq, s, e0, e1);
+    else launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_U8>(c, wg, grid, nseq, s, e0, e1);
 }
 
 // chain: the g frames are consecutive frames of ONE persistence recurrence (frame j + 1 blends with frame j's state); else independent frames.
@@ -1105,7 +1108,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_SPLIT_FROM: if (value < 0) return fail(c, CRTFX_E_INVALID, "split_from %d < 0", value); c->split_from = value; break;
     case CRTFX_OPT_GROUP: if (value < 0 || value > MAX_GROUP) return fail(c, CRTFX_E_INVALID, "group %d outside 0..%d", value, MAX_GROUP); c->opt_group = value; break;
     case CRTFX_OPT_SEG_ROWS: if (value < 0) return fail(c, CRTFX_E_INVALID, "seg_rows %d < 0", value); c->opt_seg_rows = value ? ((value + NB - 1) / NB) * NB : 0; break;
-    case CRTFX_OPT_WARP_ROWS: if (value != 1 && value != 2 && value != 4) return fail(c, CRTFX_E_INVALID, "warp rows must be 1, 2 or 4"); c->warp_rows = value; break;
+    case CRTFX_OPT_WARP_ROWS: if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, CRTFX_E_INVALID, "warp rows must be 0 (automatic), 1, 2 or 4"); c->warp_rows = value; break;
     case CRTFX_OPT_POINT_TILES: if (value < 0 || value > 16) return fail(c, CRTFX_E_INVALID, "point tiles outside 0..16"); c->point_tiles = value; break;
     case CRTFX_OPT_DEBUG_PLAN: c->debug_plan = value != 0; break;
     case CRTFX_OPT_OVERLAP:

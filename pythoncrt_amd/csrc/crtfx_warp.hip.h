@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void k_warp(KParams P, KWarpGroup G, int ident
 // blend NONE or RENDER.  Image dtype, blend mode and pixel format are compile-time, so the body is straight-line
 // code: the four tap loads issue back to back and nothing waits on a branch (the general k_warp carries
 // eight runtime paths; hipcc puts an s_waitcnt vmcnt(0) in front of every branch that contains a load).
-// ROWS output rows per thread (y, y + 4, ...): the gathers of all of them are issued before the first is used.
+// ROWS output rows per thread (y, y + 4 / WX, ...): the gathers of all of them are issued before the first is used —
+// the kernel is bound by the fabric traffic of its float32 source, and what it needs from its shape is loads in flight:
+// without a persistence state in registers 4 rows (16 pixel loads per thread) in a 128 x 8 tile measure 51.4 - 52.3 us per
+// 2-frame 4K launch against 56.4 - 56.6 for 2 rows in 64 x 8 (64 x 16: 52.7 - 53.7; 8 rows: 66 - 68, the occupancy goes).
 struct WarpTaps { F3 A, B, C, D; float u00, u01, u10, u11; };
 __device__ __forceinline__ WarpTaps warp_load(const KParams& P, const float* __restrict__ pre, int ix, int iy, int fx, int fy) {
     WarpTaps t;
@@ -153,15 +156,18 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 // record names a state buffer of its own: crtfx_process_batch's local_states).  Same operations in the same order per
 // pixel as one launch per frame: the same bits.  Other blends: nseq = 1, blockIdx.z = frame.
 // IDENT: no warp — the commit alone (a persistence blend behind the Gaussian chain with warp off): the tap is the pixel itself.
-template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false>
+// WX: waves side by side in a block's tile — (64 * WX) pixels x (4 / WX * ROWS) rows, a thread's rows 4 / WX apart.
+template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1>
 __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int nseq) {
+    constexpr int WY = 4 / WX;
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const int z0 = BLEND == CRTFX_BLEND_RENDER ? 0 : (int)blockIdx.z;
     const int nf = BLEND == CRTFX_BLEND_RENDER ? nseq : 1;
     const int lane = threadIdx.x & 63;
-    const int x0 = blockIdx.x * TW;
-    const int ybase = blockIdx.y * (4 * ROWS) + (threadIdx.x >> 6);
-    if (ybase >= P.H) return;
+    const int wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * WX + wv % WX) * TW;
+    const int ybase = blockIdx.y * (WY * ROWS) + wv / WX;
+    if (ybase >= P.H || x0 >= P.W) return;
     // (s_setprio 1 / 3 once the taps have been requested — a wave whose taps have arrived drains ahead of the waves still
     // issuing loads — measured slower: 59.2 / 60.8 vs 56.6 us per 2-frame 4K launch.)
     const int x = min(x0 + lane, P.W - 1);
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
     uint32_t off_a[ROWS], off_b[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-        const int y = min(ybase + 4 * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
+        const int y = min(ybase + WY * r, P.H - 1);           // a row past the bottom redoes the last one; its stores are skipped
         if constexpr (IDENT) {
             u00[r] = 1.0f; u01[r] = u10[r] = u11[r] = 0.0f;
             off_a[r] = off_b[r] = ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 12u;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
         const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int y = min(ybase + 4 * r, P.H - 1);
+            const int y = min(ybase + WY * r, P.H - 1);
             st[r] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
         }
     }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            const int y = ybase + 4 * r;
+            const int y = ybase + WY * r;
             if (y >= P.H) break;                                  // wave-uniform
             const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
             T v0, v1, v2;
