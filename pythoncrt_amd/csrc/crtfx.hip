@@ -347,24 +347,30 @@ void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3
     else { if (render) launch_point_lean2<SF_FAST, CRTFX_BLEND_RENDER>(c, grid, block, s, e0, e1, kf, ko); else launch_point_lean2<SF_FAST, CRTFX_BLEND_NONE>(c, grid, block, s, e0, e1, kf, ko); }
 }
 
+#ifndef WL_SEQ
+#define WL_SEQ MAX_GROUP
+#endif
 template <bool PROMOTE, int BLEND, int PIX>
-void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     // frames without a persistence chain: 4 rows per thread in a 128 x 8 tile; with one (the float32 state of every row in registers
     // as well): 2 rows, 64 x 8 — 1080p, 5 frames per launch: 40.0 against 46.7 us with 4 rows (profiles/r03_ct_ablation.txt, E)
     constexpr int WX = BLEND == CRTFX_BLEND_RENDER ? 1 : 2;
     const int rows = c->warp_rows ? c->warp_rows : (BLEND == CRTFX_BLEND_RENDER ? 2 : 4);      // output rows per thread
+    // frames a thread takes one after the other, its map coordinates and weights computed once: all of the group (WL_SEQ: dev A/B)
+    const int nseq = BLEND == CRTFX_BLEND_RENDER ? ntot : min(WL_SEQ, ntot);
     grid.x = (grid.x + WX - 1) / WX;
     grid.y = (c->H + (4 / WX) * rows - 1) / ((4 / WX) * rows);
+    grid.z = (ntot + nseq - 1) / nseq;
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
-    if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-    else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
-    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq); }
+    if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
+    else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
+    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
 }
 template <bool PROMOTE, int BLEND>
-void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int nseq, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    if (c->pix_fmt == CRTFX_PIX_F16) launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_F16>(c, wg, grid, nseq, s, e0, e1);
-    else launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_U8>(c, wg, grid, nseq, s, e0, e1);
+void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (c->pix_fmt == CRTFX_PIX_F16) launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_F16>(c, wg, grid, ntot, s, e0, e1);
+    else launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_U8>(c, wg, grid, ntot, s, e0, e1);
 }
 
 // chain: the g frames are consecutive frames of ONE persistence recurrence (frame j + 1 blends with frame j's state); else independent frames.
@@ -385,12 +391,12 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
         if (rend) grid.z = 1;       // the g frames of a persistence chain: one after the other inside each thread, the state in registers
         if (identity) {             // no warp behind the Gaussian chain: the blend and the commit only
             grid.y = (c->H + 7) / 8;
-            if (prom) { CRTFX_LAUNCH((k_warp_lean<true, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g); }
-            else { CRTFX_LAUNCH((k_warp_lean<false, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g); }
+            if (prom) { CRTFX_LAUNCH((k_warp_lean<true, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
+            else { CRTFX_LAUNCH((k_warp_lean<false, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
             return;
         }
-        if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
-        else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, 1, s, pe.e0, pe.e1); }
+        if (prom) { if (rend) launch_warp_lean<true, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<true, CRTFX_BLEND_NONE>(c, wg, grid, g, s, pe.e0, pe.e1); }
+        else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, g, s, pe.e0, pe.e1); }
         return;
     }
     if (chain && g > 1) {           // a persistence chain on the general kernel: its frames commit strictly in order (ref:1081-1105)
