@@ -348,7 +348,7 @@ void launch_point_lean(crtfx_ctx* c, bool pixelate, bool render, dim3 grid, dim3
 }
 
 #ifndef WL_SEQ
-#define WL_SEQ MAX_GROUP
+#define WL_SEQ 1
 #endif
 template <bool PROMOTE, int BLEND, int PIX>
 void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
@@ -356,16 +356,19 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
     // as well): 2 rows, 64 x 8 — 1080p, 5 frames per launch: 40.0 against 46.7 us with 4 rows (profiles/r03_ct_ablation.txt, E)
     constexpr int WX = BLEND == CRTFX_BLEND_RENDER ? 1 : 2;
     const int rows = c->warp_rows ? c->warp_rows : (BLEND == CRTFX_BLEND_RENDER ? 2 : 4);      // output rows per thread
-    // frames a thread takes one after the other, its map coordinates and weights computed once: all of the group (WL_SEQ: dev A/B)
+    // frames a thread takes one after the other: all of a persistence chain (the state stays in registers).  Without a blend one frame per
+    // thread (WL_SEQ = 1): sharing the map coordinates and weights between the frames of a group (WL_SEQ > 1) keeps them live across
+    // the frame loop — 164 VGPRs instead of 70, 3 waves per SIMD — and measures 56 - 65 against 52.8 - 53.9 us per 2-frame 4K launch
+    constexpr bool SEQ = BLEND == CRTFX_BLEND_RENDER || WL_SEQ > 1;
     const int nseq = BLEND == CRTFX_BLEND_RENDER ? ntot : min(WL_SEQ, ntot);
     grid.x = (grid.x + WX - 1) / WX;
     grid.y = (c->H + (4 / WX) * rows - 1) / ((4 / WX) * rows);
     grid.z = (ntot + nseq - 1) / nseq;
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
-    if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
-    else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
-    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
+    if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
+    else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
+    else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
 }
 template <bool PROMOTE, int BLEND>
 void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {

@@ -154,17 +154,17 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 // map coordinates and weights are computed once, and the float32 state (12 + 12 bytes per pixel and frame, more than
 // the frame's own 12 + 3) is read for the first frame and written behind the last one only (or behind every frame whose
 // record names a state buffer of its own: crtfx_process_batch's local_states).  Same operations in the same order per
-// pixel as one launch per frame: the same bits.  Frames without a blend take the same route for the geometry alone: the map
-// coordinates, weights and offsets are 60 % of a pixel's instructions (1080p, 5 frames per launch: 33.8 us against 45.6 with one
-// frame per thread; 4K, 2 frames: 64.0 against 74.6 on the same box).
+// pixel as one launch per frame: the same bits.  SEQ = false (frames without a blend): one frame per thread, nf = 1 at compile time —
+// the geometry is 60 % of a pixel's instructions, but keeping it in registers across a frame loop costs more occupancy than it saves
+// issue slots (profiles/r03_ct_ablation.txt, E).
 // IDENT: no warp — the commit alone (a persistence blend behind the Gaussian chain with warp off): the tap is the pixel itself.
 // WX: waves side by side in a block's tile — (64 * WX) pixels x (4 / WX * ROWS) rows, a thread's rows 4 / WX apart.
-template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1>
+template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1, bool SEQ = true>
 __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int nseq, int ntot) {
     constexpr int WY = 4 / WX;
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const int z0 = (int)blockIdx.z * nseq;                   // BLEND_RENDER: one z slice
-    const int nf = min(nseq, ntot - z0);
+    const int nf = SEQ ? min(nseq, ntot - z0) : 1;          // !SEQ: launched with nseq = 1
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int x0 = (blockIdx.x * WX + wv % WX) * TW;
