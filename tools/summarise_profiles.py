@@ -86,7 +86,7 @@ from pythoncrt_amd import _lib as _build
 
 def kernel_avg_cost():
     """{demangled kernel name: average measured issue cycles per VALU wave-instruction} for the kernels the PMC passes saw."""
-    R = next((int(m.group(1)) for k in pmc for m in [re.search(r"k_phosphor_(?:cc|rr)<(\d+)", k)] if m), 9)
+    R = next((int(m.group(1)) for k in pmc for m in [re.search(r"k_phosphor_(?:cc|ct|rr)<(\d+)", k)] if m), 9)
     out = {}
     with tempfile.TemporaryDirectory() as td:
         for src, extra in (("crtfx_rr.hip", [f"-DRR_R={R}"]), ("crtfx.hip", [])):
