@@ -29,8 +29,9 @@ def static_mix(path):
     cost-weighted SIMD cycles (average cycles per VALU wave-instruction of that kernel)."""
     out, name, n, cyc = {}, None, 0, 0.0
     for l in open(path).read().splitlines():
-        if l and not l[0].isspace() and l.rstrip().endswith(":") and not l.startswith((".", ";")):
-            name, n, cyc = l.rstrip()[:-1], 0, 0.0
+        lab = re.match(r"^([A-Za-z_$][\w$.]*):", l)       # "name:   ; @name" — local labels start with '.'
+        if lab:
+            name, n, cyc = lab.group(1), 0, 0.0
             continue
         if l.startswith(".Lfunc_end") and name:
             out[name] = (n, cyc)
