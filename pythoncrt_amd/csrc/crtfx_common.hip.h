@@ -349,11 +349,13 @@ __device__ __forceinline__ bool promotes(const KParams& P) {
     return (P.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
 }
 
-// a15 — cv2.convertScaleAbs(alpha=255): saturate(round-half-even(|(float)x * 255|))
+// a15 — cv2.convertScaleAbs(alpha=255): saturate(round-half-even(|(float)x * 255|)).  v_cvt_pk_u8_f32 rounds to nearest-even and
+// saturates to 0..255: the same function as (int)rintf + clamp for every float32 (tools/ubench/cvt_pk_u8_test.hip, see quant_u8x3).
 __device__ __forceinline__ uint32_t quant_u8(float v) {
+    uint32_t d = 0;
     const float s = fabsf(v * 255.0f);
-    const int r = (int)rintf(s);
-    return (uint32_t)min(max(r, 0), 255);
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(d) : "v"(s));
+    return d;
 }
 
 // a15 of one RGB pixel packed r | g<<8 | b<<16 with three v_cvt_pk_u8_f32: the instruction rounds to nearest-even and
@@ -474,7 +476,7 @@ __device__ __forceinline__ PackedPix commit_pixel(const KOut& O, uint32_t pix, T
     }
     PackedPix pk;
     if (O.pix == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
-    else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+    else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
     return pk;
 }
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ F3 point_finish(const KParams& P, const KFrame& F, co
     if (O.out_u8 && row_live) {
         PackedPix pk;
         if (O.pix == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
-        else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+        else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
         store_row_pix(O, (size_t)y * P.W + x0, lane, min(64, P.W - x0), pk);
     }
     return F3{f0, f1, f2};
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
                 if (O.out_u8) {
                     PackedPix pk;
                     if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
-                    else { pk.lo = quant_u8(f0) | (quant_u8(f1) << 8) | (quant_u8(f2) << 16); pk.hi = 0; }
+                    else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
                     store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
                 }
             }
