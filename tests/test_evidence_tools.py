@@ -1,0 +1,62 @@
+"""The tools that turn rocprofv3 output into the bench line's roofline evidence (tools/isa_cost.py, bench.source_hash): their
+parsing, on CPU.  A silent fallback here changes a committed number (round 3: function labels with a trailing comment were not
+recognised and every kernel was priced at the 2.9-cycle default)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+ISA = """\t.text
+\t.protected\t_ZN5crtfx6k_demoEv ; -- Begin function _ZN5crtfx6k_demoEv
+\t.globl\t_ZN5crtfx6k_demoEv
+\t.type\t_ZN5crtfx6k_demoEv,@function
+_ZN5crtfx6k_demoEv:                     ; @_ZN5crtfx6k_demoEv
+; %bb.0:
+\ts_load_dwordx2 s[0:1], s[4:5], 0x0
+\tv_fma_f32 v0, v1, v2, v3
+\tv_pk_fma_f32 v[0:1], v[2:3], s[0:1], v[0:1]
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+\tv_cvt_f64_f32_e32 v[4:5], v0
+\tds_read_b32 v6, v7
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+\t.size\t_ZN5crtfx6k_demoEv, .Lfunc_end0-_ZN5crtfx6k_demoEv
+_ZN5crtfx7k_emptyEv:
+\ts_endpgm
+.Lfunc_end1:
+"""
+
+
+def test_static_mix_reads_function_labels_with_trailing_comments(tmp_path):
+    import isa_cost
+    p = tmp_path / "demo.s"
+    p.write_text(ISA)
+    mix = isa_cost.static_mix(str(p))
+    assert set(mix) == {"_ZN5crtfx6k_demoEv", "_ZN5crtfx7k_emptyEv"}
+    n, cyc = mix["_ZN5crtfx6k_demoEv"]
+    assert n == 3                                   # the three v_ instructions; local labels do not start a function
+    assert abs(cyc - (isa_cost.cost("v_fma_f32") + isa_cost.cost("v_pk_fma_f32") + isa_cost.cost("v_cvt_f64_f32_e32"))) < 1e-9
+    assert mix["_ZN5crtfx7k_emptyEv"] == (0, 0.0)
+
+
+def test_every_priced_mnemonic_has_a_positive_cost():
+    import isa_cost
+    for m in ("v_fma_f32", "v_pk_fma_f32", "v_add_f64", "v_cvt_pk_u8_f32", "v_readlane_b32", "v_mov_b32_e32", "v_unknown_op"):
+        assert isa_cost.cost(m) > 0
+    assert isa_cost.cost("s_waitcnt") == 0.0 and isa_cost.cost("ds_read_b32") == 0.0
+
+
+def test_source_hash_covers_every_kernel_source():
+    """bench.py nulls profiles/traffic.json / valu.json figures measured on other sources: the hash must move with any file
+    the library is built from."""
+    import bench
+    from pythoncrt_amd import _lib
+    names = {os.path.basename(p) for p in _lib.SOURCES}
+    for f in os.listdir(_lib.CSRC):
+        if f.endswith((".hip", ".h")):
+            assert f in names, f"{f} is compiled into libcrtfx.so but not part of SOURCES / the evidence hash"
+    assert "crtfx.h" in names
+    h = bench.source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0
