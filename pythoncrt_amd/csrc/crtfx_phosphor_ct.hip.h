@@ -43,34 +43,13 @@ namespace crtfx {
 #ifndef CT_WAVES
 #define CT_WAVES 4        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for, radii <= 12
 #endif
-// CT_EXP: timing experiments of build/ab libraries (tools/ab_ct.sh), NEVER part of the product build (refused unless
-// CRTFX_TIMING_EXPERIMENT is defined too): each bit removes one part of a trip's work — the frames are then WRONG — to measure
-// what that part costs at full occupancy.  1 blur FMAs, 2 the A phase, 4 the pre-warp stores, 8 the helper wave's tiles, 16 the
-// tail behind img + s * blur, 32 the loop's barriers, 128 the A phase's frame loads only (conversion + staging writes stay),
-// 256 the stores go to a 64 KB window of the scratch image (same instructions, no fabric traffic), 1024 every strip takes the
-// byte-wise A phase and the two-gather triad (the slow path), 2048 the vignette and grain tiles alias the ring (8 KB less LDS:
-// what would a fifth resident block buy?).  Results: profiles/r03_ct_ablation.txt.
-#ifndef CT_EXP
-#define CT_EXP 0
-#endif
-#ifndef CT_A1_PACKED
-#define CT_A1_PACKED 0    // A/B: u / 255 of two bytes at a time with v_pk_mul_f32 + v_pk_fma_f32 (same roundings per byte): 16 VALU instructions
-#endif                    // fewer per consumer wave and trip, no faster (113.6 - 115.4 scalar vs 114.1 - 115.5 packed): packed float32 costs what two scalars cost
+// The ablation builds behind profiles/r03_ct_ablation.txt (-DCT_EXP=n: one part of a trip removed, frames wrong, timing only), the
+// a1-from-an-LDS-table and packed-a1 variants lived in this file up to the commit that recorded their results; they are not part of
+// the product source (git log -S CT_EXP -- this file).
 #ifndef CT_WARM_SKIP
 #define CT_WARM_SKIP 1    // skip the taps and the tail of the trips whose output rows all lie above the block's segment (window fill only)
 #endif
-#ifndef CT_NLUT
-#define CT_NLUT 0         // A/B: a1 (u / 255.0 of a stored byte) from a 256-entry LDS table — one shift + one gather instead of convert + multiply + fma:
-#endif                    // 8 % fewer VALU instructions, 32 % more LDS operations, 3 % SLOWER (profiles/r03_ct_ablation.txt): VALU and LDS are co-bound
 
-#if CT_EXP && !defined(CRTFX_TIMING_EXPERIMENT)
-#error "CT_EXP builds write wrong frames: timing experiments only (-DCRTFX_TIMING_EXPERIMENT)"
-#endif
-#if CT_EXP & 32
-#define CT_BARRIER() do {} while (0)
-#else
-#define CT_BARRIER() __syncthreads()
-#endif
 // a frame-row window in dwords, at most: (staged pixels + 2 * 8 of aberration) * 3 bytes, + 3 of alignment slack, + 1
 __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3 + 5) / 4 + 1; }
 // the centre ring: CT_RING_ROWS rows (a power of two >= R + 2 NB for every radius this kernel serves) of TW dwords
@@ -78,7 +57,7 @@ constexpr int CT_RING_ROWS = 32;
 __host__ __device__ constexpr int ct_ring_words(int R) { return CT_RING_ROWS * TW; }
 // LDS words: staging, one H-row tile, two tables, the centre ring, vignette tile (f64), two grain tiles (f32): 38.8 KB at R = 9
 __host__ __device__ constexpr int ct_lds_words(int R) {
-    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + (CT_NLUT ? 256 : 0) + ((CT_EXP & 2048) ? 0 : NB * TW * 2 + 2 * NB * TW);
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + NB * TW * 2 + 2 * NB * TW;
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 12 ? CT_WAVES : (R <= 20 ? 3 : 2); }
 
@@ -119,15 +98,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   composite tables T_m0, T_m1 — or lut_g, lut_inv
     constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [32][TW] dword          centre ring: frame-row window dwords (fast path) / packed centre pixels (byte-wise path)
-    constexpr uint32_t NLUT_B = RING_B + ct_ring_words(R) * 4;               // [256] float (CT_NLUT)   u / 255.0
-#if CT_EXP & 2048
-    constexpr uint32_t GVIG_B = RING_B;
-    constexpr uint32_t GN_B = RING_B + NB * TW * 8 < RING_B + ct_ring_words(R) * 4 - 2 * NB * TW * 4 ? RING_B + NB * TW * 8 : RING_B;
-#else
-    constexpr uint32_t GVIG_B = NLUT_B + (CT_NLUT ? 1024 : 0);               // [NB][TW] double         vignette gain tile
+    constexpr uint32_t GVIG_B = RING_B + ct_ring_words(R) * 4;               // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
     static_assert(GN_B + 2 * NB * TW * 4 == (uint32_t)ct_lds_words(R) * 4, "LDS map and ct_lds_words disagree");
-#endif
     static_assert(SWS - SWP >= 4, "the dword A phase parks the bytes it does not stage in the four pad floats behind a staging plane");
     float* stg = smem;
     float* hrow = smem + HROW_B / 4;
@@ -165,9 +138,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     const int px_lo = x0 - pad - aab, px_hi = x0 - pad + SWP - 1 + aab;      // first / last frame column the window touches
     const bool interior = px_lo >= 0 && px_hi <= W - 1 && (W & 3) == 0;
     bool fast = P.triad_comp != nullptr && __builtin_amdgcn_readfirstlane((int)votes) != 0 && interior;      // block-uniform, and known to be: a scalar branch
-#if CT_EXP & 1024
-    fast = false;
-#endif
     const uint32_t a_lo = ((uint32_t)(px_lo > 0 ? px_lo : 0) * 3u) & ~3u;    // the window's first byte in a frame row, dword-aligned
     const int ND = interior ? (int)(((uint32_t)px_hi * 3u + 2u - a_lo) / 4u) + 1 : 1;      // its dwords (<= NDMAX)
     {
@@ -175,9 +145,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const float* t1 = fast ? P.triad_comp + LUT_N : P.lut_inv;
         for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = t0[i]; lut[LUT_STRIDE + i] = t1[i]; }
     }
-#if CT_NLUT
-    if (tid < 256) LDS_AT(lds_f32_t, NLUT_B + ((uint32_t)tid << 2)) = norm_u8((uint32_t)tid);
-#endif
     const float* taps = P.taps;
     // the taps as R + 1 aligned SGPR pairs (tap[2m], tap[2m+1]); see k_phosphor_cc
     unsigned long long tp[R + 1];
@@ -197,22 +164,11 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     // rounding boundary: its bits beyond the mantissa repeat f's own eight; checked with exact rationals on the host, and
     // against k_phosphor_cc's table of IEEE quotients on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
     auto a1 = [&](uint32_t u) -> float {
-#if CT_NLUT
-        return LDS_AT(lds_f32_t, NLUT_B + (u << 2));
-#else
         const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f);
-#endif
     };
     // two bytes at once: the multiply and the fma as ONE packed instruction each (v_pk_mul_f32, v_pk_fma_f32) — the same two roundings per byte
     auto a1x2 = [&](uint32_t u0, uint32_t u1, float& o0, float& o1) {
-#if CT_A1_PACKED
-        const f32x2 fu = {(float)u0, (float)u1};
-        const f32x2 lo = fu * f32x2{-0x1.fdfdfep-33f, -0x1.fdfdfep-33f};
-        const f32x2 r = __builtin_elementwise_fma(fu, f32x2{0x1.010102p-8f, 0x1.010102p-8f}, lo);
-        o0 = r[0]; o1 = r[1];
-#else
         o0 = a1(u0); o1 = a1(u1);
-#endif
     };
     // -- byte-wise A phase (k_phosphor_cc's): source element offsets of wave-item q for this lane (block-invariant)
     auto a_offsets = [&](int q, uint32_t& o_r, uint32_t& o_g, uint32_t& o_b) {
@@ -227,11 +183,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int y = min(max(hb + it / SWP, 0), H - 1);                          // BORDER_REPLICATE
         const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
-#if CT_EXP & 128
-        return RawRGB{(ro + o_r) & 255u, (ro + o_g) & 255u, (ro + o_b) & 255u};
-#else
         return load_raw(0, F.in, ro + o_r, ro + o_g, ro + o_b);
-#endif
     };
     auto a_write = [&](int q, uint32_t crow0s, RawRGB v) {      // crow0s: byte offset of the ring row of this trip's first staged row, before the shift
         const int it = min((q << 6) + lane, NB * SWP - 1);
@@ -264,11 +216,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     };
     auto f_load = [&](const FItem& it, int hb) -> uint32_t {
         const int y = min(max(hb + (int)it.j, 0), H - 1);                         // BORDER_REPLICATE
-#if CT_EXP & 128
-        return (uint32_t)y * row_elems + it.ld;
-#else
         return *reinterpret_cast<const uint32_t*>(F.in + ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));
-#endif
     };
     auto f_write = [&](const FItem& it, uint32_t crow0s, uint32_t d) {
         LDS_AT(lds_u32_t, RING_B + ((crow0s + it.rq) & RING_MASK)) = d;      // the raw window dword
@@ -298,9 +246,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         for (int qq = 0; qq < NQ; ++qq) {
             const f32x4 vv = vq[qq];
             const f32x2 vp[2] = {{vv[0], vv[1]}, {vv[2], vv[3]}};
-#if CT_EXP & 1
-            acc2[qq & 3].x += vv[0] + vv[1]; acc2[qq & 3].y += vv[2] + vv[3]; (void)vp; (void)off;
-#else
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -310,7 +255,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     else if (t >= 1 && t <= 2 * R) PK_TAPS(acc2[pp], vp[e >> 1], (e & 1) != 0, t);
                     else if (t == 2 * R + 1) acc2[pp].y = fmaf(vp[e >> 1][e & 1], taps[0], acc2[pp].y);      // tap[2R] == tap[0]
                 }
-#endif
         }
         float* hp = hrow + j * CC_HROW + 8 * g8 * 3 + c;
 #pragma unroll
@@ -352,10 +296,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) acc[jp] = f32x2{0.0f, 0.0f};
                 if (!warm) {
-#if CT_EXP & 1
-#pragma unroll
-                for (int i = 0; i < L; ++i) { if (i & 1) acc[(i >> 1) & 3].y += win2[i >> 1][1]; else acc[(i >> 1) & 3].x += win2[i >> 1][0]; }
-#else
 #pragma unroll
                 for (int i = 0; i < L; ++i)
 #pragma unroll
@@ -365,7 +305,6 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                         else if (t >= 1 && t <= 2 * R) PK_TAPS(acc[jp], win2[i >> 1], (i & 1) != 0, t);
                         else if (t == 2 * R + 1) acc[jp].y = fmaf(win2[i >> 1][i & 1], taps[0], acc[jp].y);       // tap[2R] == tap[0]
                     }
-#endif
                 }
 #pragma unroll
                 for (int jp = 0; jp < NB / 2; ++jp) { blur[2 * jp] = acc[jp].x; blur[2 * jp + 1] = acc[jp].y; }
@@ -465,17 +404,14 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     }
                 }
                 STAMP(4);
-#if !(CT_EXP & 2)
                 stage(crow0);                               // A(n): the data requested one trip ago -> staging tile + ring
                 prefetch(hb + NB);
-#endif
                 STAMP(0);
-                CT_BARRIER();
+                __syncthreads();
                 STAMP(1);
                 // ---- phase 2: C2 of block n-1 (output rows yb + j), stage by stage over the eight rows ----
                 CC_PRIO(CC_P_C2);
                 const uint32_t gt_b = GN_B + (uint32_t)(((n & 1) ^ 1) * NB * TW * 4) + gcol4;
-#if !(CT_EXP & 16)
                 if (!warm) {
                     float gnv[NB];
                     double gv[NB];
@@ -493,20 +429,11 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                         v[j] = (float)d;
                     }
                 }
-#else
-                (void)gt_b; (void)slv;
-#endif
                 {
                     uint32_t boff = off0;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-#if CT_EXP & 4
-                        asm volatile("" :: "v"(v[j]), "v"(boff));
-#elif CT_EXP & 256
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, (boff < 0xF0000000u ? (boff & 0xFFFFu) : boff), 0, 0);
-#else
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff, 0, 0);
-#endif
                         boff += row_b;
                     }
                 }
@@ -515,7 +442,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 h_pass(wave);
                 CC_PRIO(CC_P_A);
                 STAMP(2);
-                CT_BARRIER();
+                __syncthreads();
                 STAMP(3);
             }
             // ---- drain: C1 and C2 of the last block ----
@@ -600,19 +527,14 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             };
             for (int n = 0; n < n_iter; ++n, hb += NB, crow0 = (crow0 + NB * TW * 4) & RING_MASK) {
                 // ---- phase 1: a9 vignette gain of block n-1's pixels; its share of A(n) ----
-#if !(CT_EXP & 8)
                 if (!(CT_WARM_SKIP && hb - R <= y_begin)) vig_tile(hb - NB - R);        // rows above the segment: never consumed
-#endif
                 STAMP(4);
-#if !(CT_EXP & 2)
                 stage(crow0);
                 prefetch(hb + NB);
-#endif
                 STAMP(0);
-                CT_BARRIER();
+                __syncthreads();
                 STAMP(1);
                 // ---- phase 2: a11 grain sample * scale of block n's pixels (consumed next trip) ----
-#if !(CT_EXP & 8)
                 float* gw = gn + (n & 1) * NB * TW;
                 if (!(CT_WARM_SKIP && hb - R + NB <= y_begin)) {
 #pragma unroll
@@ -622,10 +544,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                         gw[j * TW + lane] = z * P.noise_scale;
                     }
                 }
-#endif
                 STAMP(6);
                 STAMP(2);
-                CT_BARRIER();
+                __syncthreads();
                 STAMP(3);
             }
             vig_tile(hb - NB - R);
