@@ -279,7 +279,7 @@ bool lean_ok(const crtfx_ctx* c, const KFrame& kf, const KOut& ko) {
 }
 
 constexpr int CC_MIN_RADIUS = 8;
-constexpr int CT_MAX_RADIUS = 12;      // k_phosphor_ct serves the four-blocks-per-CU radii; beyond them (3 / 2 blocks per CU, register-bound) k_phosphor_cc stays
+constexpr int CT_MAX_RADIUS = 15;      // k_phosphor_ct keeps four blocks per CU up to radius 15 (4 - 6 VGPRs spilled from 13); at 16 the window no longer fits 128 VGPRs (169 spills): k_phosphor_cc
 // The column-owner kernels: k_phosphor_ct for radii 1 .. CT_MAX_RADIUS (round 3: ahead of the register-window kernel at every radius
 // measured — 1080p R = 4: 63.6 vs 69.7 us per 5-frame launch, 4K R = 9: 113 vs 126), k_phosphor_cc from CC_MIN_RADIUS up where ct does not serve
 bool use_cc(const crtfx_ctx* c, int R) {

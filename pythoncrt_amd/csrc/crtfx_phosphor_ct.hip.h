@@ -41,7 +41,8 @@
 namespace crtfx {
 
 #ifndef CT_WAVES
-#define CT_WAVES 4        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for, radii <= 12
+#define CT_WAVES 4        // resident blocks per CU (= waves per SIMD) the register allocator is asked to leave room for (radii 13 .. 15: with 4 - 6 VGPRs spilled,
+                          // still 15 - 20 % ahead of three blocks without spills)
 #endif
 // The ablation builds behind profiles/r03_ct_ablation.txt (-DCT_EXP=n: one part of a trip removed, frames wrong, timing only), the
 // a1-from-an-LDS-table and packed-a1 variants lived in this file up to the commit that recorded their results; they are not part of
@@ -59,7 +60,7 @@ __host__ __device__ constexpr int ct_ring_words(int R) { return CT_RING_ROWS * T
 __host__ __device__ constexpr int ct_lds_words(int R) {
     return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + NB * TW * 2 + 2 * NB * TW;
 }
-__host__ __device__ constexpr int ct_min_waves(int R) { return R <= 12 ? CT_WAVES : (R <= 20 ? 3 : 2); }
+__host__ __device__ constexpr int ct_min_waves(int R) { return R <= 15 ? CT_WAVES : (R <= 20 ? 3 : 2); }
 
 template <int RT>
 __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KParams Pin, KGroup G, int seg_rows) {

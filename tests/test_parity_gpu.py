@@ -455,7 +455,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
-        for sigma in (3.0, 1.2, 2.0, 5.0, 10.0):
+        for sigma in (3.0, 1.2, 2.0, 4.4, 5.0, 5.5, 10.0):      # radii 9, 4, 6, 13, 15 (k_phosphor_ct; from 13 with a few spilled registers), 16, 30 (k_phosphor_cc)
             a = (frame, 0.6, tm, 2.2, False, 1, sigma, 0.25, 0.0, 1.5, vg, 2.0, 1.25, False, 1, 0, 0.0)
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3))
             res.append(pc.apply_static_effects(*a, noise_seed=7, frame_index=3, warp_strength=0.15))
@@ -530,8 +530,8 @@ def test_composite_triad_tables(pc, triad, hw, monkeypatch):
 
 
 @pytest.mark.parametrize("ab", [0, 2, -1, -3, 5, 8, -8])
-@pytest.mark.parametrize("w", [700, 1028])
-def test_ct_frame_row_windows(pc, ab, w, monkeypatch):
+@pytest.mark.parametrize("w,sigma", [(700, 3.0), (1028, 3.0), (700, 5.0), (1028, 0.4)])      # radii 9, 15 (the widest window), 1
+def test_ct_frame_row_windows(pc, ab, w, sigma, monkeypatch):
     """k_phosphor_ct's dword A phase reads each strip's staged row segment as ONE window of the frame row, R and B displaced by the
     aberration (ref:571-577): every shift the CLI admits (-8 .. 8, ref:1230) and none, on frames wide enough for interior strips
     (window inside the frame) next to edge strips (byte-wise path: BORDER_REPLICATE + wrap), against k_phosphor_cc bit for bit and
@@ -541,7 +541,7 @@ def test_ct_frame_row_windows(pc, ab, w, monkeypatch):
     h = 26
     dev = torch.device("cuda", torch.cuda.current_device())
     clip = np.stack([make_frame(h, w, seed=90 + i, kind="noise" if i else "grad") for i in range(2)])
-    rs = RenderSettings(fast_bloom=False, bloom_sigma=3.0, pixel_size=1, persistence=0.5, aberration_px=ab)     # persistence: the chain parks a pre-warp image
+    rs = RenderSettings(fast_bloom=False, bloom_sigma=sigma, pixel_size=1, persistence=0.5, aberration_px=ab)     # persistence: the chain parks a pre-warp image
     got = {}
     for name, opts in (("ct", {"FORCE_CC": 1}), ("cc", {"FORCE_CC": 1, "NO_CT": 1})):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
