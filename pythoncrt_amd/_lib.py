@@ -118,7 +118,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
 
 
 def build_variant(name: str, extra_flags, radii=(9,), main_tu: bool = False) -> str:
-    """Dev A/B builds (tools/ab_ct.sh; never the product library): build/ab/libcrtfx_<name>.so = the in-tree library's objects with the
+    """Dev A/B builds (tools/ab.sh; never the product library): build/ab/libcrtfx_<name>.so = the in-tree library's objects with the
     translation units of `radii` (and crtfx.hip when main_tu) recompiled with extra_flags.  Load one with CRTFX_LIB=<path>."""
     build()
     hipcc = "hipcc" if _which("hipcc") else "/opt/rocm/bin/hipcc"
