@@ -16,6 +16,6 @@ for i in $(seq ${PASSES:-2}); do
 for o in "$@"; do
   args=""; for kv in $o; do args="$args --opt $kv"; done
   python3 $R/bench.py $B $args 2>/dev/null | line "in-tree [$FL] ${o:-default}"
-  for L in $R/build/ab/*.so; do [ -e "$L" ] && CRTFX_LIB=$L python3 $R/bench.py $B $args 2>/dev/null | line "$(basename $L) [$FL] ${o:-default}"; done
+  for L in $R/build/ab/*.so; do if [ -e "$L" ]; then CRTFX_LIB=$L python3 $R/bench.py $B $args 2>/dev/null | line "$(basename $L) [$FL] ${o:-default}"; fi; done
 done; done
 } 2>&1 | tee -a $OUT/${TAG}_ab.txt
