@@ -106,7 +106,7 @@ CT_SIZES = [(40, 704), (26, 1028), (9, 512), (64, 322), (17, 960), (130, 260), (
 @pytest.mark.parametrize("case", range(32))
 def test_random_full_chain_on_the_headline_kernel(case):
     """The gate set of BASELINE configs 2-5 (scanlines + triad LUTs + Gaussian bloom + vignette + grain, warp or persistence behind
-    it) is what k_phosphor_ct serves: 32 seeded draws of everything that varies INSIDE that gate set — bloom radius 1..12, strengths,
+    it) is what k_phosphor_ct serves: 32 seeded draws of everything that varies INSIDE that gate set — bloom radius 1..15, strengths,
     triad strength / softness (two-valued, three-valued and unsoftened masks), aberration -8..8, scanline period / phase, frame sizes with
     interior strips, edge strips, partial last strips and widths that are not a multiple of four — through the render loop against the
     oracle's in-order render.  No warp: frame 0 bit-exact (it is the quantised pre-warp image) and the blended frames <= 1 LSB."""
@@ -119,7 +119,7 @@ def test_random_full_chain_on_the_headline_kernel(case):
     warp = pick(0.0, 0.0, 0.15)
     rs = RenderSettings(
         scanline_strength=pick(0.3, 0.6, 1.0), triad_strength=pick(0.2, 0.35, 0.5, 1.0), triad_gamma=pick(2.2, 1.8, 0.6), triad_preserve_luma=False,
-        triad_softness=pick(0.0, 0.5, 1.0, 2.0), aberration_px=int(rng.integers(-8, 9)), bloom_sigma=pick(0.2, 0.5, 1.0, 1.2, 2.0, 2.7, 3.0, 3.7, 4.0),
+        triad_softness=pick(0.0, 0.5, 1.0, 2.0), aberration_px=int(rng.integers(-8, 9)), bloom_sigma=pick(0.2, 0.5, 1.0, 1.2, 2.0, 2.7, 3.0, 3.7, 4.0, 4.4, 4.6, 5.0),      # radii 1 .. 15: all on k_phosphor_ct (13 .. 15 with spilled registers)
         bloom_strength=pick(0.1, 0.25, 0.9), bloom_threshold=0.0, noise_strength=pick(0.5, 1.5, 6.0), vignette_strength=pick(0.1, 0.25, 1.0),
         persistence=(pick(0.2, 0.5) if warp == 0.0 else pick(0.0, 0.5)), scanline_speed_px_s=pick(30.0, -12.5, 7.0), scanline_period_px=pick(2.0, 3.7),
         fast_bloom=False, pixel_size=1, warp_strength=warp)
