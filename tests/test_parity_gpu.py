@@ -391,6 +391,23 @@ def test_errors_are_loud(pc):
         pc.apply_static_effects(*a[:6], 30000.0, *a[7:])                                     # radius 90000: past the tap array's sanity bound
 
 
+def test_option_values_are_checked(pc, monkeypatch):
+    """crtfx_set_option refuses values outside what include/crtfx.h documents (the error text names the limit); a refused switch
+    leaves no half-configured ctx behind: the next engine with valid switches works."""
+    from pythoncrt_amd import _lib, effects
+    frame = make_frame(48, 64)
+    a = [frame, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0]
+    for bad, pat in (({"WARP_ROWS": 3}, "warp rows"), ({"WARP_ROWS": -1}, "warp rows"), ({"GROUP": 99}, "."), ({"POINT_TILES": 17}, ".")):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(bad))
+        effects._tls.engines = {}
+        with pytest.raises(_lib.CrtfxError, match=pat):
+            pc.apply_static_effects(*a)
+    monkeypatch.setattr(effects, "DEBUG_OPTIONS", {"WARP_ROWS": 0, "GROUP": 2})
+    effects._tls.engines = {}
+    pc.apply_static_effects(*a, warp_strength=0.15)
+    effects._tls.engines = {}
+
+
 # ---- BASELINE full sizes: size-independent properties ------------------------------------------
 
 @pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840)])
