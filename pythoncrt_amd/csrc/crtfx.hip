@@ -63,6 +63,7 @@ struct crtfx_ctx {
     bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
     bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
+    bool no_plain_warp = false;      // CRTFX_OPT_NO_PLAIN_WARP: k_warp_lean's branch-free build off (tests, A/B)
     bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
     bool debug_plan = false;
@@ -366,6 +367,12 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
     grid.z = (ntot + nseq - 1) / nseq;
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
+    // the headline shape — unblended uint8 frames, none of which keeps a float state, rows of whole dwords — on the branch-free build
+    if constexpr (BLEND == CRTFX_BLEND_NONE && PIX == CRTFX_PIX_U8 && !SEQ) {
+        bool plain = rows == 4 && (c->W & 3) == 0 && !c->no_plain_warp;
+        for (int j = 0; j < ntot && plain; ++j) plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr;
+        if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
+    }
     if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
     else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
     else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
@@ -1112,6 +1119,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
     case CRTFX_OPT_NO_CT: c->no_ct = value != 0; break;
+    case CRTFX_OPT_NO_PLAIN_WARP: c->no_plain_warp = value != 0; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
     case CRTFX_OPT_SPLIT_SRC_PLANE: c->split_src_plane = value != 0; break;
     case CRTFX_OPT_SPLIT_FROM: if (value < 0) return fail(c, CRTFX_E_INVALID, "split_from %d < 0", value); c->split_from = value; break;

@@ -410,6 +410,9 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out, size_t r
 // The same through a raw buffer resource over the output frame (k_warp_lean; frame bytes < 2^31): 32-bit offsets, and the
 // dwords past the row segment's end are given an out-of-range offset, which the hardware drops — no byte tail, no 64-bit
 // address arithmetic.  Needs the segment dword-aligned with a whole number of dwords (W % 4 == 0); else the byte form.
+// AUX: the store's cache-policy bits (2 = nt: a frame that is written once and never read back by the GPU should not take
+// Infinity-Cache lines from the pre-warp images its kernel is still reading — profiles/r04_warp_ablation.txt)
+template <int AUX = 0>
 __device__ __forceinline__ void store_row_u8_buf(__amdgpu_buffer_rsrc_t rs, uint32_t row_byte0, int lane, int valid_px, uint32_t packed, bool aligned) {
     if (aligned) {                           // wave-uniform
         const int j = lane;                // dword index in the 192-byte segment
@@ -420,12 +423,12 @@ __device__ __forceinline__ void store_row_u8_buf(__amdgpu_buffer_rsrc_t rs, uint
         const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 24);
         const uint32_t dw = (uint32_t)(v >> (8 * o));
         const uint32_t off = (4 * j + 4 <= valid_px * 3) ? row_byte0 + 4u * (uint32_t)j : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_buffer_store_b32(dw, rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(dw, rs, off, 0, AUX);
     } else {
         const uint32_t off = lane < valid_px ? row_byte0 + 3u * (uint32_t)lane : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)packed, rs, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 8), rs, off + 1u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 16), rs, off + 2u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)packed, rs, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 8), rs, off + 1u, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(packed >> 16), rs, off + 2u, 0, AUX);
     }
 }
 

@@ -25,6 +25,17 @@ __device__ __forceinline__ void warp_coords(const KParams& P, int y, int x, int&
 }
 
 
+// a*wa + b*wb + c*wc + d*wd, left to right as cv2.remap sums it.  In double every product of a float32 tap and a float32 weight is EXACT
+// (24 + 24 significant bits <= 53), so fma(b, wb, a * wa) rounds the same real number as a * wa + b * wb does: one v_mul_f64 + three
+// v_fma_f64 per channel instead of four multiplies and three adds (36 of 84 float64 instructions per thread of four pixels), same bits.
+// In float the products round, so the float image keeps the multiply-then-add form.
+__device__ __forceinline__ double wsum4(double a, double wa, double b, double wb, double c, double wc, double d, double wd) {
+    return fma(d, wd, fma(c, wc, fma(b, wb, a * wa)));
+}
+__device__ __forceinline__ float wsum4(float a, float wa, float b, float wb, float c, float wc, float d, float wd) {
+    return ((a * wa + b * wb) + c * wc) + d * wd;
+}
+
 // The four taps are loaded unconditionally from CLAMPED addresses (always inside the image) as
 // 12-byte vectors, all four in flight together; a tap that lies outside the image is then
 // replaced by the border value 0 (cv2.remap BORDER_CONSTANT), exactly what OpenCV's border
@@ -50,9 +61,10 @@ __device__ __forceinline__ void warp_sample(const KParams& P, const float* __res
     // zeroed (4 selects) instead of its three channel values (12)
     const float u00 = (xin0 && yin0) ? w00 : 0.0f, u01 = (xin1 && yin0) ? w01 : 0.0f;
     const float u10 = (xin0 && yin1) ? w10 : 0.0f, u11 = (xin1 && yin1) ? w11 : 0.0f;
-    o0 = (((T)A.x * (T)u00 + (T)B.x * (T)u01) + (T)C.x * (T)u10) + (T)D.x * (T)u11;
-    o1 = (((T)A.y * (T)u00 + (T)B.y * (T)u01) + (T)C.y * (T)u10) + (T)D.y * (T)u11;
-    o2 = (((T)A.z * (T)u00 + (T)B.z * (T)u01) + (T)C.z * (T)u10) + (T)D.z * (T)u11;
+    const T t00 = (T)u00, t01 = (T)u01, t10 = (T)u10, t11 = (T)u11;
+    o0 = wsum4((T)A.x, t00, (T)B.x, t01, (T)C.x, t10, (T)D.x, t11);
+    o1 = wsum4((T)A.y, t00, (T)B.y, t01, (T)C.y, t10, (T)D.y, t11);
+    o2 = wsum4((T)A.z, t00, (T)B.z, t01, (T)C.z, t10, (T)D.z, t11);
 }
 
 #ifdef CRTFX_MAIN_TU
@@ -143,9 +155,10 @@ __device__ __forceinline__ F3 buf_load_px(__amdgpu_buffer_rsrc_t rs, uint32_t of
 }
 template <typename T>
 __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T& o2) {
-    o0 = (((T)t.A.x * (T)t.u00 + (T)t.B.x * (T)t.u01) + (T)t.C.x * (T)t.u10) + (T)t.D.x * (T)t.u11;
-    o1 = (((T)t.A.y * (T)t.u00 + (T)t.B.y * (T)t.u01) + (T)t.C.y * (T)t.u10) + (T)t.D.y * (T)t.u11;
-    o2 = (((T)t.A.z * (T)t.u00 + (T)t.B.z * (T)t.u01) + (T)t.C.z * (T)t.u10) + (T)t.D.z * (T)t.u11;
+    const T w00 = (T)t.u00, w01 = (T)t.u01, w10 = (T)t.u10, w11 = (T)t.u11;
+    o0 = wsum4((T)t.A.x, w00, (T)t.B.x, w01, (T)t.C.x, w10, (T)t.D.x, w11);
+    o1 = wsum4((T)t.A.y, w00, (T)t.B.y, w01, (T)t.C.y, w10, (T)t.D.y, w11);
+    o2 = wsum4((T)t.A.z, w00, (T)t.B.z, w01, (T)t.C.z, w10, (T)t.D.z, w11);
 }
 
 // nseq: the frames of G that each thread takes ONE AFTER THE OTHER (slice blockIdx.z of the group's ntot frames).  The persistence recurrence
@@ -159,8 +172,15 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 // issue slots (profiles/r03_ct_ablation.txt, E).
 // IDENT: no warp — the commit alone (a persistence blend behind the Gaussian chain with warp off): the tap is the pixel itself.
 // WX: waves side by side in a block's tile — (64 * WX) pixels x (4 / WX * ROWS) rows, a thread's rows 4 / WX apart.
-template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1, bool SEQ = true>
-__global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int nseq, int ntot) {
+// PLAIN: what the launcher has checked for the whole group — uint8 frames out (never null), no state to keep, W % 4 == 0 — so the body has no
+// branch at all: a row past the bottom redoes the last one and its dword stores land beyond the output buffer's range (dropped by the
+// hardware), and the sixteen tap loads of a thread issue before the first interpolation.
+#ifndef WARP_PLAIN_WAVES
+#define WARP_PLAIN_WAVES 1
+#endif
+template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1, bool SEQ = true, bool PLAIN = false>
+__global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_lean(KParams P, KWarpGroup G, int nseq, int ntot) {
+    static_assert(!PLAIN || (BLEND == CRTFX_BLEND_NONE && PIX == CRTFX_PIX_U8 && !IDENT && !SEQ), "PLAIN: unblended uint8 frames behind a warp");
     constexpr int WY = 4 / WX;
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const int z0 = (int)blockIdx.z * nseq;                   // BLEND_RENDER: one z slice
@@ -194,7 +214,8 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
         // clamps keep the offset arithmetic inside 32 bits: iy to [-2, H] (both rows of the pair stay outside when iy is), ix to
         // [-1, W] (the masks above come from the unclamped ix)
         const int ixc = min(max(ix, -1), P.W), iyc = min(max(iy, -2), P.H);
-        off_a[r] = (uint32_t)(iyc * P.W + ixc) * 12u;        // a negative offset (rows -2, -1) wraps far past the buffer's end
+        // 24-bit multiplies (|iyc| <= 32767, W * 12 < 2^19, |ixc| <= 32767): v_mad_i32_i24 at half the cost of the 64-bit multiply-add hipcc forms for the 32-bit product
+        off_a[r] = (uint32_t)(__mul24(iyc, P.W * 12) + __mul24(ixc, 12));        // a negative offset (rows -2, -1) wraps far past the buffer's end
         off_b[r] = off_a[r] + (uint32_t)P.W * 12u;
     }
     F3 st[ROWS];
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int y = ybase + WY * r;
-            if (y >= P.H) break;                                  // wave-uniform
+            if constexpr (!PLAIN) { if (y >= P.H) break; }        // wave-uniform
             const uint32_t pix = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
             T v0, v1, v2;
             if constexpr (IDENT) { v0 = (T)taps[r].A.x; v1 = (T)taps[r].A.y; v2 = (T)taps[r].A.z; }
@@ -238,12 +259,17 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
             }
             const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
             if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = F3{f0, f1, f2};
+            if constexpr (PLAIN) {
+                // row y >= H: ((y * W + x0) * 3 >= H * W * 3, the buffer's size: every dword of the row is dropped
+                store_row_u8_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 3u) + (uint32_t)x0 * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), true);
+                continue;
+            }
             if (O.state && live && keep_state) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};
             if (O.out_u8) {
                 if constexpr (PIX == CRTFX_PIX_F16) {
                     store_row_f16(O.out_u8, (size_t)y * P.W + x0, lane, min(64, P.W - x0), PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
                 } else {
-                    store_row_u8_buf(out_rs, ((uint32_t)y * (uint32_t)P.W + (uint32_t)x0) * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), (P.W & 3) == 0);
+                    store_row_u8_buf<2>(out_rs, ((uint32_t)y * (uint32_t)P.W + (uint32_t)x0) * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), (P.W & 3) == 0);
                 }
             }
         }

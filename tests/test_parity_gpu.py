@@ -468,7 +468,8 @@ def test_kernel_variants_agree(pc, monkeypatch):
     outs = {}
     for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("cc_no_ct", {"FORCE_CC": 1, "NO_CT": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}),
                        ("split", {"SPLIT_FROM": 0}), ("split_plane", {"SPLIT_FROM": 0, "SPLIT_SRC_PLANE": 1}),
-                       ("warp_rows_1", {"WARP_ROWS": 1}), ("warp_rows_2", {"WARP_ROWS": 2}), ("warp_rows_4", {"WARP_ROWS": 4})):      # k_warp_lean's tile shapes (0 = the launcher's choice)
+                       ("warp_rows_1", {"WARP_ROWS": 1}), ("warp_rows_2", {"WARP_ROWS": 2}), ("warp_rows_4", {"WARP_ROWS": 4}),      # k_warp_lean's tile shapes (0 = the launcher's choice)
+                       ("no_plain_warp", {"NO_PLAIN_WARP": 1})):      # ... and its general build where the branch-free one is the default
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
@@ -495,7 +496,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(keep.cpu().numpy())      # the per-frame states the sharded render's fix-up reads (written even when a run keeps its state in registers)
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("cc", "cc_no_ct", "no_cc", "runtime_flags", "generic", "split", "split_plane", "warp_rows_1", "warp_rows_2", "warp_rows_4"):
+    for name in ("cc", "cc_no_ct", "no_cc", "runtime_flags", "generic", "split", "split_plane", "warp_rows_1", "warp_rows_2", "warp_rows_4", "no_plain_warp"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
 
