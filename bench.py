@@ -99,6 +99,27 @@ def copy_ceiling(device):
     return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
+def mall_ceiling(device, group_bytes):
+    """GB/s (source + output bytes) of reading back a float32 buffer the size of one launch group's pre-warp images RIGHT AFTER it was
+    written, while writing a quarter of the bytes as uint8 — k_warp's situation: its source is kept under the 256 MB Infinity Cache on
+    purpose, so the HBM-sized copy above is the wrong yardstick for it (profiles/r04_warp_ablation.txt A: the hand-written streams of
+    tools/ubench/mall_copy.hip reach 6.6-6.8 TB/s at 199 MB; this is torch's own fill + converting copy, a lower bound on the same thing)."""
+    n = max(1, int(group_bytes) // 4)
+    a = torch.empty(n, dtype=torch.float32, device=device)
+    o = torch.empty(n, dtype=torch.uint8, device=device)
+    tot = 0.0
+    for i in range(7):
+        a.fill_(0.5)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o.copy_(a)
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+            tot += e0.elapsed_time(e1)
+    return round(5 * 5 * n / (tot * 1e-3) / 1e9, 1)
+
+
 def source_hash():
     """Fingerprint of the device code a PMC measurement belongs to (profiles/traffic.json carries the same field):
     sha1 over the kernel sources, so that a stale traffic figure is never attached to a different build."""
@@ -291,9 +312,11 @@ def main():
         "metric": "4K frames/sec (whole node) + achieved HBM GB/s as % of MI355X peak" if a.config == 3 else f"{h}p frames/sec (whole node)",
         "value": round(fps_out, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic",      # the arithmetic type of the chain up to the vignette; config.arithmetic says what runs after it
         "config": {"workload": (f"BASELINE configs[{a.config - 1}]" if a.config else "reference CLI defaults (fast bloom, pixel_size 2)") + f": {w}x{h} chain (scanlines+triad+aberration+bloom sigma={rs.bloom_sigma}"
                                f"+warp {rs.warp_strength}+vignette+grain), persistence {p}, {'fp16' if a.config == 5 else 'u8'} in/out",
+                   "arithmetic": "float32 through the bloom, triad and scanline stages; float64 for the vignette / flicker / grain tail and the warp's "
+                                 "bilinear sums (NumPy's promotion, ref:626-647), narrowed to float32 where a value is stored",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-shard x{world}"},
         "timed_region_s": round(dt, 4),
         **({"tuning_options": dict(effects.DEBUG_OPTIONS)} if effects.DEBUG_OPTIONS else {}),
@@ -404,6 +427,8 @@ def main():
                 "fabric_frac_as_reported": round(traffic_raw / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_raw else None,
                 "valu": valu, "lds": lds,
                 "copy_ceiling": copy_ceiling(device),
+                # ... and what reading one launch group's float32 pre-warp images back out of the Infinity Cache reaches (k_warp's yardstick)
+                "mall_ceiling": mall_ceiling(device, px * 12 * fpl) if rs.warp_strength != 0.0 else None,
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
             }

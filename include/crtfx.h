@@ -221,7 +221,8 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   FORCE_GENERIC        always take the general-purpose kernels (the LDS-ring k_phosphor, k_point, k_warp)
  *   FORCE_RUNTIME_FLAGS  never take a gate-folded instantiation
  *   NO_CC                full-chain launches that park a pre-warp image stay on k_phosphor_rr (A/B against k_phosphor_cc)
- *   FORCE_CC             ... take k_phosphor_cc for every radius and both pixel formats (it is the default only where it is faster)
+ *   FORCE_CC             ... take the column-owner family for every radius (k_phosphor_ct where it is built — uint8 frames, radii 1..15 —
+ *                        unless NO_CT is set, k_phosphor_cc elsewhere); by default k_phosphor_cc serves radii 16..30 only
  *   NO_CT                ... stay on k_phosphor_cc instead of its composite-table build k_phosphor_ct (A/B)
  *   GROUP, SEG_ROWS      frames per grid (1..8 = CRTFX_MAX_GROUP) / rows per block of the register-window kernels; 0 = the planner's choice
  *   WARP_ROWS            output rows per k_warp_lean thread (1, 2, 4; 0 = the launcher's choice: 4, or 2 with a persistence chain)

@@ -305,13 +305,16 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     bool folded = (gates == SF_FULL || pix_fold) && !c->force_runtime_flags;
     if ((c->kp.flags & CRTFX_F_NOISE) && c->kp.grain > 1) folded = false;
     for (int j = 0; j < g; ++j) if (kg.f[j].scan_plane || kg.f[j].overlay_before || kg.o[j].overlay_after) folded = false;
-    // the column-owner kernel takes the full-chain launches that park a pre-warp image (warp and / or persistence behind them)
-    // — for uint8 frames and radii >= CC_MIN_RADIUS, where it is the faster build (4K, R = 9: 134 vs 140 us per 2-frame launch;
-    // R = 5 / 6 / 7 within 1-3 % the other way; 1080p, R = 4: 64 vs 60; 8K half frames: 288 vs 284: profiles/r02_cc_ab.txt).  Its stores address a frame's scratch
-    // image with 32-bit byte offsets.
+    // the column-owner kernels take the full-chain launches of uint8 frames that park a pre-warp image (warp and / or persistence behind
+    // them): k_phosphor_ct for radii 1 .. CT_MAX_RADIUS = 15, k_phosphor_cc above (use_cc; against the register-window kernel k_phosphor_cc
+    // alone paid from radius 8 only — profiles/r02_cc_ab.txt — ct pays at every radius, profiles/r03_ct_ablation.txt).  Their stores address a
+    // frame's scratch image with 32-bit byte offsets.
     bool cc = folded && !pix_fold && !c->no_cc && use_cc(c, R);
     for (int j = 0; j < g && cc; ++j) cc = kg.o[j].pre != nullptr;
-    const bool ct = cc && !c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS;       // the dword-load / composite-table build of the same kernel (uint8 frames)
+    bool ct = cc && !c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS;       // the dword-load / composite-table build of the same kernel (uint8 frames)
+    // ... whose A phase reads a frame row as aligned dwords: a caller's frame that does not start on a 4-byte boundary (an odd base pointer
+    // or frame stride through the C-ABI; torch allocations never are) takes the byte-wise k_phosphor_cc — same bits
+    for (int j = 0; j < g && ct; ++j) ct = ((uintptr_t)kg.f[j].in & 3u) == 0;
     int& seg_slot = c->seg_for[ct ? 3 : cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, ct ? 2 : cc ? 1 : 0).seg;   // planned once per (kernel build, group size)
     const int seg = seg_slot;
@@ -325,8 +328,9 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     table[R](c->kp, kg, seg, dim3(strips, segs, g), lds, s, variant, pe.e0, pe.e1);
 }
 
-// Radii 1..12 (sigma up to ~4.1; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run the
-// register-window kernel; anything else (radius 0 = 1-tap copy, or > 12) the generic LDS-ring one.
+// Radii 1 .. 30 (sigma up to 10; the CLI default 1.2 -> 4, BASELINE config 3 sigma 3 -> 9) run a fused build (launch_rr_group: the
+// column-owner kernels k_phosphor_ct / k_phosphor_cc or the register-window kernel k_phosphor_rr); radius 0 (a 1-tap copy), injected
+// per-pixel planes and FORCE_GENERIC the generic LDS-ring kernel; larger radii never get here (the split bloom, crtfx_set_params).
 void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t s) {
     if (lean_ok(c, kf, ko)) {
         KGroup kg{};
@@ -695,12 +699,14 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         size_t cnt[2] = {0, 0};
         {   // the two most frequent bit patterns: a softened period-3 mask has two or three interior values plus a few border ones
             std::vector<std::pair<uint32_t, size_t>> hist;
-            for (size_t i = 0; i < (size_t)W * 3; ++i) {
+            bool many = false;                          // a mask with 64 or more distinct values is not a period-3 row: no composite form, no tables built
+            for (size_t i = 0; i < (size_t)W * 3 && !many; ++i) {
                 uint32_t b; std::memcpy(&b, row + i, 4);
                 size_t j = 0;
                 for (; j < hist.size(); ++j) if (hist[j].first == b) { ++hist[j].second; break; }
-                if (j == hist.size()) { if (hist.size() >= 64) break; hist.emplace_back(b, 1); }      // a mask with that many values is not a period-3 row: no composite form
+                if (j == hist.size()) { if (hist.size() >= 64) many = true; else hist.emplace_back(b, 1); }
             }
+            if (many) hist.clear();
             for (auto& h : hist) {
                 if (h.second > cnt[0]) { vals[1] = vals[0]; cnt[1] = cnt[0]; vals[0] = h.first; cnt[0] = h.second; }
                 else if (h.second > cnt[1]) { vals[1] = h.first; cnt[1] = h.second; }

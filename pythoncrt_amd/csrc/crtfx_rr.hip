@@ -28,7 +28,7 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         }                                                                                                                 \
     } while (0)
 #if RR_R <= 15
-    if (variant == 6) {     // as variant 4 on the dword-load / composite-table build (k_phosphor_ct, radii <= 12)
+    if (variant == 6) {     // as variant 4 on the dword-load / composite-table build (k_phosphor_ct, radii 1 .. 15 = CT_MAX_RADIUS)
         CRTFX_LAUNCH((k_phosphor_ct<RR_R>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
         return;
     }

@@ -170,14 +170,24 @@ class DeviceState:
     def tensor(self) -> torch.Tensor:
         """The device tensor (float32 H x W x 3); re-uploaded first if the host copy was modified through this object."""
         if self._dirty:
-            self._t = torch.from_numpy(np.ascontiguousarray(self._host)).to(self._t.device)
+            self._t = torch.from_numpy(np.array(self._host, dtype=np.float32, order="C")).to(self._t.device)
             self._dirty = False
         return self._t
 
-    def numpy(self) -> np.ndarray:
+    def _host_rw(self) -> np.ndarray:
         if self._host is None:
             self._host = self._t.cpu().numpy()
         return self._host
+
+    def numpy(self) -> np.ndarray:
+        """The float32 host array, READ-ONLY: every array this object hands out (np.asarray, indexing, ndarray attributes) is a
+        non-writeable view of its cached host copy, so a write the object cannot see — `np.asarray(state)[...] = x`,
+        `state.fill(0)`, `np.clip(..., out=np.asarray(state))` — raises instead of silently leaving the device tensor stale.
+        Write through the object itself (`state[k] = v`: uploaded again before the next tick) or take a copy (`np.array(state)`)
+        and pass that back as `state_prev`."""
+        v = self._host_rw().view()
+        v.flags.writeable = False
+        return v
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
@@ -192,7 +202,7 @@ class DeviceState:
         return self.numpy()[k]
 
     def __setitem__(self, k, v):
-        self.numpy()[k] = v
+        self._host_rw()[k] = v
         self._dirty = True
 
     def __getattr__(self, name):                # anything else an ndarray has (astype, mean, min, T, tobytes, ...)

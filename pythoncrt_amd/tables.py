@@ -6,11 +6,12 @@ factor, pixelate index maps.  The per-pixel work lives in the HIP kernels.  Wher
 (crt_filter.py, `ref:LINE`) computes a table with numpy, the same numpy expression is used so
 the values are this machine's numpy values (np.sin / np.power are not bit-portable across CPUs).
 
-Restated reference expressions.  Four helpers necessarily repeat lines of crt_filter.py (PythonCRT, GPL-3.0), because the
-product must draw the same random numbers in the same order and evaluate the same numpy expression tree to be bit-exact with
-it: `glitch_offsets_preview` (ref:670-679) and `glitch_offsets_render_segments` (ref:841-850) — the PCG64 seed formula and the
-order of the Generator calls; `scanline_plane` (ref:317-328) and `grade_lut` (ref:292-304) — the float32 / float64 expression
-order.  Each cites its lines; nothing else in this package is taken from the reference's text.
+Restated reference expressions.  Three helpers necessarily repeat lines of crt_filter.py (PythonCRT, GPL-3.0 — see NOTICE at the
+repository root), because the product must draw the same random numbers in the same order and evaluate the same numpy expression
+tree to be bit-exact with it: `glitch_offsets_preview` (ref:670-679) and `glitch_offsets_render_segments` (ref:841-850) — the PCG64
+seed formula and the order of the Generator calls; `grade_lut` (ref:292-304) — the float32 / float64 expression order.  Each cites
+its lines; nothing else in this package is taken from the reference's text.  (The 2-D scanline mask, ref:317-328, is written on the
+device by crtfx_scanline_plane; its numpy form lives in the oracle only.)
 """
 from __future__ import annotations
 
@@ -131,19 +132,6 @@ def scanline_rows_at(k: np.ndarray, strength: float, period_px: float) -> np.nda
     k = np.asarray(k, dtype=np.float32)
     s = 0.5 * (1.0 + np.sin((2.0 * np.pi / max(1e-6, period_px)) * k))
     return np.ascontiguousarray(1.0 - strength * s)
-
-
-def scanline_plane(h: int, w: int, strength: float, period_px: float, phase_px: float, angle_deg: float, thickness: float) -> np.ndarray:
-    """make_scanline_mask_2d (ref:308-328) — only used when angle != 0 or thickness != 1."""
-    if strength <= 0.0:
-        return np.ones((h, w), dtype=np.float32)
-    yy, xx = np.mgrid[0:h, 0:w]
-    theta = np.deg2rad(float(angle_deg))
-    slanted = yy + np.tan(theta) * xx
-    omega = 2.0 * np.pi / max(1e-6, float(period_px))
-    s = 0.5 * (1.0 + np.sin(omega * (slanted + float(phase_px))))
-    sharp = np.clip(float(thickness), 0.1, 4.0)
-    return np.ascontiguousarray((1.0 - float(strength) * np.power(s, 1.0 / sharp)).astype(np.float32))
 
 
 def grade_lut(brightness: float, contrast: float, gamma: float, temperature: float) -> np.ndarray:

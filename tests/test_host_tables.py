@@ -106,7 +106,6 @@ def test_vignette_warp_scanline_tables():
     rows = tables.scanline_rows(720, 0.6, 2.0, phases)
     for r, ph in zip(rows, phases):
         assert np.array_equal(r, orc.make_scanline_mask_dynamic(720, 0.6, 2.0, ph))
-    assert np.array_equal(tables.scanline_plane(24, 40, 0.6, 2.0, 1.25, 5.0, 1.8), orc.make_scanline_mask_2d(24, 40, 0.6, 2.0, 1.25, 5.0, 1.8))
     assert tables.flicker_factor(0.5, 7.0, 0.3) == float(1.0 + 0.25 * 0.5 * np.sin(2.0 * np.pi * 7.0 * 0.3))
 
 
@@ -218,3 +217,14 @@ def test_device_state_is_an_array_like():
     assert _as_device_tensor(st, torch.device("cpu"), torch.float32, None, "state_prev").data_ptr() == st.tensor.data_ptr()
     st[0, 0, :] = 0.25
     assert np.array_equal(st.tensor.numpy()[0, 0], np.full(3, 0.25, np.float32)) and np.array_equal(st.tensor.numpy()[1:], ref[1:])
+    # every array it hands out is read-only: a write the object could not see (the device tensor would go stale) raises instead
+    import pytest
+    for write in (lambda: np.asarray(st).__setitem__((1, 1, 1), 9.0), lambda: st.numpy().fill(0.0), lambda: st.fill(0.0),
+                  lambda: np.clip(st, 0.0, 0.5, out=np.asarray(st)), lambda: st[2].__setitem__(0, 1.0)):
+        with pytest.raises(ValueError):
+            write()
+    assert np.array_equal(st.tensor.numpy()[1:], ref[1:])
+    # a copy is an ordinary array: mutate it and pass it back as state_prev (the plain-ndarray path)
+    c = np.array(st)
+    c[...] = 0.5
+    assert c.flags.writeable and np.array_equal(st.tensor.numpy()[1:], ref[1:])

@@ -115,7 +115,8 @@ def cases_worker(rank, world, port, overlap, cases, outdir):
                 if out is not None:
                     keep([(r, out)])
         if overlap:
-            keep(render.flush())
+            keep(render.close())           # flush() + the staged schedule's worker thread and extra gloo groups released (collective)
+            assert render.close() == []    # idempotent: nothing in flight, nothing left to free
         assert seen == sorted(seen) and len(seen) == len(shard.my_chunks(n_frames))
         dist.barrier()
     dist.destroy_process_group()
