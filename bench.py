@@ -120,6 +120,83 @@ def mall_ceiling(device, group_bytes):
     return round(5 * 5 * n / (tot * 1e-3) / 1e9, 1)
 
 
+class GpuTelemetry:
+    """Shader clock and package power of THIS rank's GPU, sampled from a host thread while the timed region runs (librocm_smi64 through
+    ctypes — nothing on the GPU stream, no subprocess).  Why it is in the line: with eight packages drawing ~1.3 kW each at full load
+     a node-level power or thermal cap is the one plausible way for the frame-sharded path to come in under 7x at
+    8 GPUs, and per-rank frames/s alone could not tell that from a hop stall or a slow host.  Every failure degrades to nulls."""
+
+    def __init__(self, device, period_s=0.05):
+        import ctypes as C
+        import threading
+        self.err, self.samples, self._stop, self._thr = None, [], threading.Event(), None
+        self.period = period_s
+        try:
+            self.lib = C.CDLL("librocm_smi64.so")
+            if self.lib.rsmi_init(C.c_uint64(0)) != 0:
+                raise OSError("rsmi_init failed")
+            n = C.c_uint32(0)
+            self.lib.rsmi_num_monitor_devices(C.byref(n))
+            pr = torch.cuda.get_device_properties(device)
+            want = (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1), getattr(pr, "pci_device_id", 0))
+            self.idx = None
+            for i in range(n.value):
+                bdf = C.c_uint64(0)
+                if self.lib.rsmi_dev_pci_id_get(C.c_uint32(i), C.byref(bdf)) == 0:
+                    v = bdf.value
+                    if ((v >> 32) & 0xFFFFFFFF, (v >> 8) & 0xFF, (v >> 3) & 0x1F) == want:
+                        self.idx = i
+                        break
+            if self.idx is None:
+                self.idx = device.index if n.value > (device.index or 0) else 0
+                self.err = "PCI id not matched: device index used"
+
+            class Freqs(C.Structure):
+                _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
+            self._Freqs, self._C = Freqs, C
+        except Exception as e:       # noqa: BLE001 - telemetry must never take the bench down
+            self.lib, self.err = None, f"{type(e).__name__}: {e}"
+
+    def _sample(self):
+        C = self._C
+        f, pw = self._Freqs(), C.c_uint64(0)
+        mhz = watts = None
+        if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.idx), C.c_int(0), C.byref(f)) == 0 and f.current < 33:
+            mhz = f.frequency[f.current] / 1e6
+        if self.lib.rsmi_dev_current_socket_power_get(C.c_uint32(self.idx), C.byref(pw)) == 0:
+            watts = pw.value / 1e6
+        return mhz, watts
+
+    def start(self):
+        import threading
+        if self.lib is None:
+            return
+        self.samples, self._stop = [], threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(self._sample())
+                except Exception as e:       # noqa: BLE001
+                    self.err = f"{type(e).__name__}: {e}"
+                    return
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=5)
+            self._thr = None
+        clk = [m for m, _ in self.samples if m]
+        pw = [w_ for _, w_ in self.samples if w_]
+        return {"samples": len(self.samples), "period_s": self.period,
+                "sclk_mhz_mean": round(sum(clk) / len(clk), 1) if clk else None, "sclk_mhz_min": round(min(clk), 1) if clk else None,
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None,
+                **({"note": self.err} if self.err else {})}
+
+
 def source_hash():
     """Fingerprint of the device code a PMC measurement belongs to (profiles/traffic.json carries the same field):
     sha1 over the kernel sources, so that a stale traffic figure is never attached to a different build."""
@@ -270,11 +347,15 @@ def main():
     prof = not a.no_profile
     region_dt = []
     kt = {}
+    own_dt = None
+    telem = GpuTelemetry(device)
+    telem_first = None
     for reg in range(n_regions):
         first = a.warmup + reg * a.steps
         host_s[0] = 0.0
         if reg == 0:
             pipe.profile(8 if prof else 0)      # HIP events on the launches of every 8th frame of the reported region
+            telem.start()
         t0 = time.perf_counter()
         for s in range(first, first + a.steps):
             one_step(s)
@@ -282,9 +363,12 @@ def main():
         sync()
         dt_r = time.perf_counter() - t0
         if reg == 0:
+            telem_first = telem.stop()
             kt = pipe.profile_read() if prof else {}
             pipe.profile(False)
             host_first = host_s[0]
+        if reg == 0:
+            own_dt = dt_r                       # this rank's own wall time of the reported region (before the max over ranks)
         if dist is not None:
             t = torch.tensor([dt_r], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -292,12 +376,25 @@ def main():
         region_dt.append(dt_r)
     dt = region_dt[0]
 
+    # what every rank saw of the reported region — frames/s on its own clock, its GPU's shader clock and package power, its kernel
+    # time per launch group and (sharded persistence) its own hop / fix-up split: a sub-7x result at 8 GPUs can then be attributed from
+    # the line alone (throttling: sclk / power differ between ranks or from the 1-GPU line; hop stall: shard_schedule; host: frames/s
+    # below what chain_ms_per_launch_group allows)
+    kt_ok = {k: v for k, v in (kt or {}).items() if v[1] and v[2]}
+    mine_rec = {"rank": rank, "frames_per_s": round(B * a.steps / region_dt[0], 2) if region_dt else None,
+                "frames_per_s_own_clock": round(B * a.steps / own_dt, 2) if own_dt else None,
+                "chain_ms_per_frame": round(sum(v[0] * v[1] / v[2] for v in kt_ok.values()), 5) if kt_ok else None,
+                "gpu": telem_first,
+                **({"shard_schedule": render.schedule_report()} if (p > 0.0 and world > 1) else {})}
     per_rank = None
+    per_rank_detail = [mine_rec]
     if dist is not None:
         mine = torch.tensor([B * a.steps / dt], dtype=torch.float64, device=device)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         per_rank = [round(float(v.item()), 2) for v in allv]
+        per_rank_detail = [None] * world
+        dist.all_gather_object(per_rank_detail, mine_rec)
 
     total_frames = B * a.steps * world
     fps_out = total_frames / dt
@@ -324,7 +421,7 @@ def main():
                         "note": "per-frame scanline/flicker tables + frame records built and uploaded per step; they overlap the previous step's kernels"},
         "repeat_values": [round(total_frames / d, 2) for d in region_dt[1:]],
         "dist": {"backend": backend if world > 1 else None, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
-                 "per_rank_frames_per_s": per_rank},
+                 "per_rank_frames_per_s": per_rank, "per_rank": per_rank_detail},
     }
     if p > 0.0 and world > 1:
         res["shard_schedule"] = render.schedule_report()

@@ -16,8 +16,10 @@ pipe), from a file or stdin/stdout, so the drop-in sits between two ffmpeg proce
 compatibility and ignored (encode/decode/UI are not part of this path).  `--text*` rasterise the overlay on
 the host with Pillow (ref:366-414) and alpha-blend it on the GPU before or after the effects.
 
-Host staging: two pinned input and two pinned output batches; batch k's upload, kernels
-and download are enqueued on one stream while the host writes batch k-1 and reads batch k+1.
+Host staging (the reference's reader / writer pipes ref:469-514, :1003-1014, :1101): a reader thread fills pinned
+input batches, a writer thread drains pinned output batches, and the GPU side runs on THREE streams — upload, kernels, download —
+chained by events, so that batch k+1's upload, batch k's kernels and batch k-1's download are in flight together (the two PCIe
+directions are independent DMA engines) while the host reads batch k+2 and writes batch k-2.
 """
 from __future__ import annotations
 
@@ -82,6 +84,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--gui", action="store_true")
     # not in the reference
     p.add_argument("--batch", type=int, default=16, help="frames enqueued per GPU batch")
+    p.add_argument("--staging-report", action="store_true", help="print where the reader / GPU-feeding / writer threads spent their time")
     p.add_argument("--noise-seed", type=int, default=None, help="seed of the counter-based grain RNG (default: random)")
     return p
 
@@ -170,6 +173,54 @@ def _pread_full(fd: int, view: memoryview, offset: int) -> int:
     return total
 
 
+class _MappedInput:
+    """A regular input file mapped read-only: a batch is copied out of the page cache by user-space memcpy on the I/O threads
+    (numpy's copy loop releases the GIL) instead of read(2).  Measured on the GPU box, 1.6 GB from tmpfs into a pinned buffer, eight
+    threads (tools/io_rates.py): 76 GB/s — against 18 GB/s for os.preadv on the FIRST read of a freshly written file (61 GB/s on later
+    reads), which is what capped the CLI at ~700 4K frames/s whatever the GPU side did.  MADV_WILLNEED on the batch after next starts
+    the readahead of a file that is not in the page cache yet."""
+
+    def __init__(self, fd: int):
+        import mmap
+        import os
+        self.size = os.fstat(fd).st_size
+        self.map = mmap.mmap(fd, self.size, prot=mmap.PROT_READ) if self.size > 0 else None
+        self.arr = np.frombuffer(self.map, dtype=np.uint8) if self.map is not None else None
+        self._mmap = mmap
+
+    def read_into(self, dst: np.ndarray, offset: int) -> int:
+        """Fill the uint8 array `dst` from the file at `offset`; returns the bytes copied (short only at end of file)."""
+        n = max(0, min(dst.size, self.size - offset))
+        if n <= 0:
+            return 0
+        ahead = min(self.size, offset + 3 * dst.size) - (offset + n)
+        if ahead > 0 and hasattr(self._mmap, "MADV_WILLNEED"):
+            page = self._mmap.PAGESIZE
+            lo = ((offset + n) // page) * page
+            try:
+                self.map.madvise(self._mmap.MADV_WILLNEED, lo, min(self.size - lo, ahead + page))
+            except (OSError, ValueError):
+                pass
+
+        def one(lo):
+            hi = min(n, lo + _IO_SLICE)
+            np.copyto(dst[lo:hi], self.arr[offset + lo:offset + hi])
+        if n > _IO_SLICE:
+            list(_io_pool().map(one, range(0, n, _IO_SLICE)))
+        else:
+            one(0)
+        return n
+
+    def close(self):
+        self.arr = None
+        if self.map is not None:
+            try:
+                self.map.close()
+            except BufferError:         # a view of the map is still referenced somewhere: the mapping goes with the process
+                pass
+            self.map = None
+
+
 def _pwrite_full(fd: int, view: memoryview, offset: int) -> None:
     """Write `view` to `fd` at `offset` (regular file) in parallel slices."""
     import os
@@ -194,6 +245,125 @@ def _seekable(f) -> bool:
         return stat.S_ISREG(os.fstat(f.fileno()).st_mode)
     except (OSError, ValueError, AttributeError):
         return False
+
+
+class _Reader:
+    """A thread that fills pinned (B, H, W, 3) uint8 slots ahead of the GPU: `jobs` yields (byte offset | None, frames) requests — an offset
+    for positional reads of a regular file, None for the next bytes of a stream — and `get()` hands back (slot index, pinned tensor,
+    frames actually read) in order, or None at the end.  `release(i)` returns a slot once its upload has completed."""
+
+    def __init__(self, fin, positional: bool, jobs, shape, frame_bytes: int, slots: int = 3):
+        import queue
+        import threading
+        import torch
+        self.fin, self.positional, self.frame_bytes = fin, positional, frame_bytes
+        self.bufs = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.free, self.full = queue.Queue(), queue.Queue()      # the free-slot queue already bounds what is in flight
+        for i in range(slots):
+            self.free.put(i)
+        self.err = None
+        self.t_wait = self.t_io = 0.0          # seconds this thread waited for a free slot / spent reading (the --staging-report line)
+        self.mapped = None
+        if positional:
+            try:
+                self.mapped = _MappedInput(fin.fileno())
+                if self.mapped.map is None:
+                    self.mapped = None
+            except (OSError, ValueError):
+                self.mapped = None             # not mappable: positional read(2) calls instead
+
+        def loop():
+            try:
+                for off, nfr in jobs:
+                    t = time.perf_counter()
+                    i = self.free.get()
+                    self.t_wait += time.perf_counter() - t
+                    if i is None:
+                        return
+                    view = memoryview(self.bufs[i].numpy()).cast("B")[: nfr * frame_bytes]
+                    t = time.perf_counter()
+                    if self.mapped is not None:
+                        got = self.mapped.read_into(self.bufs[i].numpy().reshape(-1)[: nfr * frame_bytes], off)
+                    else:
+                        got = _pread_full(fin.fileno(), view, off) if positional else _read_into(fin, view)
+                    self.t_io += time.perf_counter() - t
+                    self.full.put((i, got // frame_bytes, got))
+                    if got < len(view):
+                        break
+            except BaseException as e:      # noqa: BLE001 - re-raised on the consumer's side
+                self.err = e
+            self.full.put(None)
+        self.thr = threading.Thread(target=loop, name="crtfx-reader", daemon=True)
+        self.thr.start()
+
+    def get(self):
+        item = self.full.get()
+        if self.err is not None:
+            raise self.err
+        return item
+
+    def release(self, i: int):
+        self.free.put(i)
+
+    def close(self):
+        self.free.put(None)
+        self.thr.join(timeout=30)
+        if self.mapped is not None:
+            self.mapped.close()
+
+
+class _Writer:
+    """A thread that waits for a download's event and writes the pinned batch out (positional for a regular file), then hands the slot
+    back.  `slot()` blocks until a pinned output slot is free; `put(i, frames, event, offset)` queues it."""
+
+    def __init__(self, fout, positional: bool, shape, frame_bytes: int, slots: int = 3):
+        import queue
+        import threading
+        import torch
+        self.bufs = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.free, self.work = queue.Queue(), queue.Queue()
+        for i in range(slots):
+            self.free.put(i)
+        self.err, self.frames = None, 0
+        self.t_wait = self.t_io = 0.0          # seconds this thread waited for downloads / spent writing
+
+        def loop():
+            while True:
+                job = self.work.get()
+                if job is None:
+                    return
+                i, n, ev, off = job
+                try:
+                    t = time.perf_counter()
+                    ev.synchronize()
+                    self.t_wait += time.perf_counter() - t
+                    view = memoryview(self.bufs[i].numpy()).cast("B")[: n * frame_bytes]
+                    t = time.perf_counter()
+                    if positional:
+                        _pwrite_full(fout.fileno(), view, off)
+                    else:
+                        fout.write(view)
+                    self.t_io += time.perf_counter() - t
+                    self.frames += n
+                except BaseException as e:      # noqa: BLE001
+                    self.err = e
+                self.free.put(i)
+        self.thr = threading.Thread(target=loop, name="crtfx-writer", daemon=True)
+        self.thr.start()
+
+    def slot(self) -> int:
+        if self.err is not None:
+            raise self.err
+        return self.free.get()
+
+    def put(self, i: int, n: int, ev, off):
+        self.work.put((i, n, ev, off))
+
+    def close(self):
+        self.work.put(None)
+        self.thr.join()
+        if self.err is not None:
+            raise self.err
 
 
 def main_sharded(a, rank: int, world: int) -> int:
@@ -234,37 +404,80 @@ def main_sharded(a, rank: int, world: int) -> int:
     # — over gloo (rehearsals).  Over RCCL the synchronous hop stays the default until the overlapped one has run on a multi-GPU
     # box (it costs ~0.3 ms per round: one state frame over one xGMI link + the fix-up); CRTFX_SHARD_OVERLAP=1 opts in.
     overlap = backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1"
-    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=2), dist=dist, overlap=overlap)
+    # three output slots: round r's frames may still be on their way to the host (download stream) while round r + 1 is scanned and —
+    # overlapped schedule, results one call late — round r + 2 is enqueued
+    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=3), dist=dist, overlap=overlap)
     if rank == 0:
         with open(a.output, "wb") as f:
             f.truncate(n_frames * frame_bytes)
     dist.barrier()
     t0 = time.perf_counter()
-    fin, fout = os.open(a.input, os.O_RDONLY), os.open(a.output, os.O_WRONLY)
-    host = torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory()
-    done = 0
+    fin, fout = open(a.input, "rb", buffering=0), open(a.output, "r+b", buffering=0)
+    n_rounds = shard.rounds(n_frames)
+    mine = [(r,) + shard.frame_range(r, n_frames) for r in range(n_rounds)]
+    reader = _Reader(fin, True, ((lo * frame_bytes, hi - lo) for _, lo, hi in mine if hi > lo), (B, h, w, 3), frame_bytes, slots=2)
+    writer = _Writer(fout, True, (B, h, w, 3), frame_bytes, slots=2)
+    compute = torch.cuda.current_stream(dev)
+    s_up, s_down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    in_free = [None, None]                                # per device input slot: the event after which the kernels no longer read it
+    downs = []                                            # download events in order of issue
 
     def commit(finished):
-        nonlocal done
         for rr, out in finished:
             flo, fhi = shard.frame_range(rr, n_frames)
-            _pwrite_full(fout, memoryview(out.cpu().numpy()).cast("B"), flo * frame_bytes)
-            done += fhi - flo
+            n = fhi - flo
+            i = writer.slot()
+            ready = torch.cuda.Event()
+            ready.record(compute)                         # the round's kernels (and fix-up) are enqueued behind this point at the latest
+            s_down.wait_event(ready)
+            with torch.cuda.stream(s_down):
+                writer.bufs[i][:n].copy_(out[:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s_down)
+            downs.append(ev)
+            writer.put(i, n, ev, flo * frame_bytes)
 
-    uploaded = torch.cuda.Event()
-    for r in range(shard.rounds(n_frames)):
-        lo, hi = shard.frame_range(r, n_frames)
+    k, pend = 0, None
+    for r, lo, hi in mine:
         frames = None
         if hi > lo:
-            uploaded.synchronize()                        # the previous chunk has left the pinned staging buffer
-            view = memoryview(host.numpy()).cast("B")[: (hi - lo) * frame_bytes]
-            if _pread_full(fin, view, lo * frame_bytes) != len(view):
+            item = reader.get()
+            if item is None or item[1] != hi - lo:
                 raise SystemExit(f"short read at frame {lo}")
-            frames = host[: hi - lo].to(dev, non_blocking=True)
-            uploaded.record()
+            i, n, _ = item
+            d = k & 1
+            if in_free[d] is not None:
+                s_up.wait_event(in_free[d])               # the kernels that read this device slot two rounds ago are done
+            with torch.cuda.stream(s_up):
+                dev_in[d][:n].copy_(reader.bufs[i][:n], non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(s_up)
+            compute.wait_event(up)
+            frames = dev_in[d][:n]
+            k += 1
+        # the engine's three output slots come round every third round: every download but the latest must have left them
+        for ev in downs[:-1]:
+            compute.wait_event(ev)
+        del downs[:-1]
         commit(render.submit_round(frames, r, active=shard.active_ranks(r, n_frames)))
+        if pend is not None:                              # the previous chunk's pinned slot: free again once its upload has completed (long done)
+            pend[0].synchronize()
+            reader.release(pend[1])
+            pend = None
+        if hi > lo:
+            pend = (up, i)
+            ev = torch.cuda.Event()
+            ev.record(compute)                            # the scan that reads dev_in[d] is enqueued by now (the fix-up reads local states only)
+            in_free[d] = ev
+    if pend is not None:
+        pend[0].synchronize()
+        reader.release(pend[1])
     commit(render.close())                                # the round still in flight; frees the staged schedule's extra process groups
-    os.close(fin); os.close(fout)
+    writer.close()
+    reader.close()
+    done = writer.frames
+    fin.close(); fout.close()
     dist.barrier()
     print(f"rank {rank}: {done} of {n_frames} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)
     dist.destroy_process_group()
@@ -300,59 +513,98 @@ def main(argv=None) -> int:
     fout = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
     B = max(1, int(a.batch))
     frame_bytes = h * w * 3
-    host_in = [torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
-    host_out = [torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
-    dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    dev_out = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    done = [torch.cuda.Event() for _ in range(2)]
     t0 = time.perf_counter()
-    state, index, k = None, 0, 0
-    pending = None                                                  # (slot, frames) of the batch still in flight
-
     # regular files: positional I/O on a few threads (a pipe / the terminal: the plain sequential calls)
     in_pos = _seekable(fin) and a.input != "-"
     out_pos = fout is not sys.stdout.buffer and _seekable(fout)
-    in_off = out_off = 0
 
-    def drain(p):
-        nonlocal out_off
-        slot, n = p
-        done[slot].synchronize()
-        view = memoryview(host_out[slot].numpy()).cast("B")[: n * frame_bytes]
-        if out_pos:
-            _pwrite_full(fout.fileno(), view, out_off)
-            out_off += len(view)
-        else:
-            fout.write(view)
-
+    def jobs():                                                     # whole batches until the stream ends (the reader stops at a short read)
+        off = 0
+        while True:
+            yield (off if in_pos else None), B
+            off += B * frame_bytes
+    NS = 3
+    reader = _Reader(fin, in_pos, jobs(), (B, h, w, 3), frame_bytes, slots=NS)
+    writer = _Writer(fout, out_pos, (B, h, w, 3), frame_bytes, slots=NS)
+    dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
+    dev_out = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
+    compute = torch.cuda.current_stream(dev)
+    s_up, s_down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    kernels_done = [None] * NS                                      # per device slot: its batch's kernels have finished (dev_in free again)
+    down_done = [None] * NS                                         # ... its download has finished (dev_out free again)
+    state, index, k, out_off, pend = None, 0, 0, 0, None
+    t_get = t_enq = t_slot = t_rel = 0.0
     while True:
-        slot = k & 1
-        if in_pos:
-            got = _pread_full(fin.fileno(), memoryview(host_in[slot].numpy()).cast("B"), in_off)
-            in_off += got
-        else:
-            got = _read_into(fin, memoryview(host_in[slot].numpy()).cast("B"))
-        n = got // frame_bytes                                      # a trailing partial frame is dropped, as ffmpeg's rawvideo demuxer does
+        tt = time.perf_counter()
+        item = reader.get()
+        t_get += time.perf_counter() - tt
+        if item is None:
+            break
+        i, n, got = item                                            # a trailing partial frame is dropped, as ffmpeg's rawvideo demuxer does
+        tt = time.perf_counter()
         if n:
-            dev_in[slot][:n].copy_(host_in[slot][:n], non_blocking=True)
-            _, state = pipe.run(dev_in[slot][:n], first_index=index, state=state, out=dev_out[slot][:n])
-            host_out[slot][:n].copy_(dev_out[slot][:n], non_blocking=True)
-            done[slot].record()
-        if pending is not None:
-            drain(pending)
-        pending = (slot, n) if n else None
+            d = k % NS
+            # upload k on its own stream, once the kernels that last read this device slot (batch k - NS) are done
+            if kernels_done[d] is not None:
+                s_up.wait_event(kernels_done[d])
+            with torch.cuda.stream(s_up):
+                dev_in[d][:n].copy_(reader.bufs[i][:n], non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(s_up)
+            # kernels k behind the upload, and behind the download that last read this output slot
+            compute.wait_event(up)
+            if down_done[d] is not None:
+                compute.wait_event(down_done[d])
+            _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
+            kd = torch.cuda.Event()
+            kd.record(compute)
+            kernels_done[d] = kd
+            # download k on the third stream into a free pinned slot; the writer thread takes it from there
+            t_enq += time.perf_counter() - tt
+            tt = time.perf_counter()
+            j = writer.slot()
+            t_slot += time.perf_counter() - tt
+            tt = time.perf_counter()
+            s_down.wait_event(kd)
+            with torch.cuda.stream(s_down):
+                writer.bufs[j][:n].copy_(dev_out[d][:n], non_blocking=True)
+                dn = torch.cuda.Event()
+                dn.record(s_down)
+            down_done[d] = dn
+            writer.put(j, n, dn, out_off if out_pos else None)
+            out_off += n * frame_bytes
+        # a pinned input slot goes back to the reader once its upload has completed: the PREVIOUS batch's is waited for here (long done),
+        # so this thread never sits on the upload it has just enqueued
+        t_enq += time.perf_counter() - tt
+        tt = time.perf_counter()
+        if pend is not None:
+            pend[0].synchronize()
+            reader.release(pend[1])
+            pend = None
+        t_rel += time.perf_counter() - tt
+        if n:
+            pend = (up, i)
+        else:
+            reader.release(i)
         index += n
         k += 1
-        if n < B:
+        if got < B * frame_bytes:
             break
-    if pending is not None:
-        drain(pending)
+    if pend is not None:
+        pend[0].synchronize()
+        reader.release(pend[1])
+    writer.close()
+    reader.close()
     fout.flush()
     if fout is not sys.stdout.buffer:
         fout.close()
     if fin is not sys.stdin.buffer:
         fin.close()
     print(f"{index} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)      # ref:1269
+    if a.staging_report:
+        print(f"staging: reader read {reader.t_io:.3f}s waited-for-slot {reader.t_wait:.3f}s | feeder waited-for-input {t_get:.3f}s enqueued {t_enq:.3f}s "
+              f"waited-for-output-slot {t_slot:.3f}s waited-for-upload {t_rel:.3f}s | writer waited-for-download {writer.t_wait:.3f}s wrote {writer.t_io:.3f}s",
+              file=sys.stderr)
     return 0
 
 

@@ -85,8 +85,8 @@ class ShardedRender:
 
         local_scan(frames, first_index, clip_start[, slot]) -> (local_states float32 (n,H,W,3), out uint8 (n,H,W,3))
             scan of the chunk from a zero incoming state (clip_start: the very first frame of the
-            clip passes through unblended, ref:1094-1095, and there is no carry at all); `slot` (0/1) names the
-            buffer pair to use when the engine double-buffers (engine.slots == 2)
+            clip passes through unblended, ref:1094-1095, and there is no carry at all); `slot` (0 .. engine.slots - 1) names the
+            buffer set to use when the engine multi-buffers (engine.slots >= 2)
         correct(local_states, carry, p, out) -> None
             out[j] = quantise(clip(local_states[j] + p^(j+1) * carry))
 
@@ -318,7 +318,7 @@ class ShardedRender:
             return done
         c = sh.chunk_of(round_index)
         first = c * sh.chunk
-        slot = round_index & 1
+        slot = round_index % max(1, int(getattr(self.engine, "slots", 1)))      # 2 slots: rounds alternate; 3 (the CLI): one more round may still be downloading
         e0 = self._ev(frames)
         if getattr(self.engine, "slots", 1) >= 2:
             local, out = self.engine.local_scan(frames, first, clip_start=(c == 0), slot=slot)

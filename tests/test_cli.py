@@ -4,6 +4,8 @@ defaults, same clamps on the way to the render settings."""
 import json
 import os
 
+import numpy as np
+
 from pythoncrt_amd import cli
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +33,7 @@ def test_flag_names_and_defaults():
     for k, v in ref.items():
         assert k in ours, k
         assert ours[k] == v, (k, ours[k], v)
-    assert set(ours) - set(ref) == {"batch", "noise_seed"}      # the two additions documented in cli.py
+    assert set(ours) - set(ref) == {"batch", "noise_seed", "staging_report"}      # the additions documented in cli.py
 
 
 def test_clamps_match_reference_main():
@@ -80,3 +82,29 @@ def test_positional_file_io_helpers(tmp_path, monkeypatch):
             assert not cli._seekable(pr)
     finally:
         os.close(w)
+
+
+def test_mapped_input_reads_like_the_file(tmp_path):
+    """cli._MappedInput — the regular-file input path (mmap + memcpy on the I/O threads instead of read(2)): whole batches, the short
+    last batch, offsets past the end, slices larger and smaller than the I/O slice, an empty file."""
+    import os
+    data = np.random.default_rng(0).integers(0, 256, 40_000_003, dtype=np.uint8)
+    path = tmp_path / "in.rgb"
+    path.write_bytes(data.tobytes())
+    fd = os.open(path, os.O_RDONLY)
+    m = cli._MappedInput(fd)
+    dst = np.empty(33_000_000, dtype=np.uint8)           # > 16 MiB: split over the pool
+    assert m.read_into(dst, 0) == dst.size and np.array_equal(dst, data[:dst.size])
+    assert m.read_into(dst, 33_000_000) == 7_000_003 and np.array_equal(dst[:7_000_003], data[33_000_000:])
+    assert m.read_into(dst, data.size) == 0 and m.read_into(dst, data.size + 5) == 0
+    small = np.empty(1000, dtype=np.uint8)
+    assert m.read_into(small, 12345) == 1000 and np.array_equal(small, data[12345:13345])
+    m.close()
+    os.close(fd)
+    empty = tmp_path / "empty.rgb"
+    empty.write_bytes(b"")
+    fd = os.open(empty, os.O_RDONLY)
+    m = cli._MappedInput(fd)
+    assert m.map is None and m.read_into(small, 0) == 0
+    m.close()
+    os.close(fd)

@@ -194,6 +194,12 @@ def test_bench_launches_its_own_ranks(config, batch):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["dist"]["world_size_seen"] == 2 and len(res["dist"]["per_rank_frames_per_s"]) == 2
     assert res["value"] > 0 and res["config"]["frames_per_step_per_gpu"] == batch
+    # every rank's own view of the reported region: frames/s on its own clock, its kernel time per frame, its GPU's clock / power samples
+    pr = res["dist"]["per_rank"]
+    assert [d["rank"] for d in pr] == [0, 1]
+    for d in pr:
+        assert d["frames_per_s_own_clock"] > 0 and d["chain_ms_per_frame"] > 0 and set(d["gpu"]) >= {"samples", "sclk_mhz_mean", "power_w_mean"}
     if config == 4:
         sr = res["shard_schedule"]
         assert sr["overlap"] and sr["parallel_hop"] and sr["rounds"] >= 2 and sr["fixup_frames"] == 26
+        assert all(d["shard_schedule"]["rounds"] == sr["rounds"] for d in pr)      # the schedule of EVERY rank, not rank 0's only
