@@ -137,7 +137,7 @@ def _read_into(fin, view: memoryview) -> int:
 
 
 _IO_POOL = None
-_IO_SLICE = 16 << 20            # bytes per positional read / write call
+_IO_SLICE = 8 << 20             # bytes per positional read / write / copy call
 
 
 def _io_pool():
@@ -147,7 +147,11 @@ def _io_pool():
     if _IO_POOL is None:
         import concurrent.futures
         import os
-        _IO_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="crtfx-io")
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cpus = os.cpu_count() or 2
+        _IO_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(16, cpus // 2)), thread_name_prefix="crtfx-io")
     return _IO_POOL
 
 
@@ -202,9 +206,22 @@ class _MappedInput:
             except (OSError, ValueError):
                 pass
 
+        page = self._mmap.PAGESIZE
+        drop = getattr(self._mmap, "MADV_DONTNEED", None)
+
         def one(lo):
             hi = min(n, lo + _IO_SLICE)
             np.copyto(dst[lo:hi], self.arr[offset + lo:offset + hi])
+            # drop the page-table entries of what this thread has copied (the pages stay in the page cache), slice by slice on the I/O
+            # threads: unmapping a 24 GB clip's worth of touched pages in one piece at the end costs the render ~0.7 s, and zapping a
+            # whole batch from the reader thread 13 ms per 400 MB — on its critical path
+            if drop is not None:
+                a0, a1 = ((offset + lo + page - 1) // page) * page, ((offset + hi) // page) * page
+                if a1 > a0:
+                    try:
+                        self.map.madvise(drop, a0, a1 - a0)
+                    except (OSError, ValueError):
+                        pass
         if n > _IO_SLICE:
             list(_io_pool().map(one, range(0, n, _IO_SLICE)))
         else:
@@ -534,6 +551,7 @@ def main(argv=None) -> int:
     down_done = [None] * NS                                         # ... its download has finished (dev_out free again)
     state, index, k, out_off, pend = None, 0, 0, 0, None
     t_get = t_enq = t_slot = t_rel = 0.0
+    marks = []
     while True:
         tt = time.perf_counter()
         item = reader.get()
@@ -547,16 +565,21 @@ def main(argv=None) -> int:
             # upload k on its own stream, once the kernels that last read this device slot (batch k - NS) are done
             if kernels_done[d] is not None:
                 s_up.wait_event(kernels_done[d])
+            tim = a.staging_report
             with torch.cuda.stream(s_up):
+                if tim:
+                    u0 = torch.cuda.Event(enable_timing=True); u0.record(s_up)
                 dev_in[d][:n].copy_(reader.bufs[i][:n], non_blocking=True)
-                up = torch.cuda.Event()
+                up = torch.cuda.Event(enable_timing=tim)
                 up.record(s_up)
             # kernels k behind the upload, and behind the download that last read this output slot
             compute.wait_event(up)
             if down_done[d] is not None:
                 compute.wait_event(down_done[d])
+            if tim:
+                k0 = torch.cuda.Event(enable_timing=True); k0.record(compute)
             _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
-            kd = torch.cuda.Event()
+            kd = torch.cuda.Event(enable_timing=tim)
             kd.record(compute)
             kernels_done[d] = kd
             # download k on the third stream into a free pinned slot; the writer thread takes it from there
@@ -567,10 +590,14 @@ def main(argv=None) -> int:
             tt = time.perf_counter()
             s_down.wait_event(kd)
             with torch.cuda.stream(s_down):
+                if tim:
+                    d0 = torch.cuda.Event(enable_timing=True); d0.record(s_down)
                 writer.bufs[j][:n].copy_(dev_out[d][:n], non_blocking=True)
-                dn = torch.cuda.Event()
+                dn = torch.cuda.Event(enable_timing=tim)
                 dn.record(s_down)
             down_done[d] = dn
+            if tim:
+                marks.append((u0, up, k0, kd, d0, dn, n))
             writer.put(j, n, dn, out_off if out_pos else None)
             out_off += n * frame_bytes
         # a pinned input slot goes back to the reader once its upload has completed: the PREVIOUS batch's is waited for here (long done),
@@ -601,6 +628,16 @@ def main(argv=None) -> int:
     if fin is not sys.stdin.buffer:
         fin.close()
     print(f"{index} frames, elapsed {time.perf_counter() - t0:.3f}s", file=sys.stderr)      # ref:1269
+    if a.staging_report and len(marks) > 4:
+        torch.cuda.synchronize()
+        mk = marks[2:]                   # past the start-up batches
+        up_ms = sum(m[0].elapsed_time(m[1]) for m in mk) / len(mk)
+        k_ms = sum(m[2].elapsed_time(m[3]) for m in mk) / len(mk)
+        dn_ms = sum(m[4].elapsed_time(m[5]) for m in mk) / len(mk)
+        span = mk[0][0].elapsed_time(mk[-1][5]) / len(mk)
+        nb = sum(m[6] for m in mk) / len(mk) * frame_bytes
+        print(f"staging (GPU side, per batch of {nb / frame_bytes:.0f} frames): upload {up_ms:.2f} ms = {nb / up_ms / 1e6:.1f} GB/s, kernels {k_ms:.2f} ms, "
+              f"download {dn_ms:.2f} ms = {nb / dn_ms / 1e6:.1f} GB/s; one batch every {span:.2f} ms = {nb / frame_bytes / span * 1e3:.0f} frames/s", file=sys.stderr)
     if a.staging_report:
         print(f"staging: reader read {reader.t_io:.3f}s waited-for-slot {reader.t_wait:.3f}s | feeder waited-for-input {t_get:.3f}s enqueued {t_enq:.3f}s "
               f"waited-for-output-slot {t_slot:.3f}s waited-for-upload {t_rel:.3f}s | writer waited-for-download {writer.t_wait:.3f}s wrote {writer.t_io:.3f}s",

@@ -48,6 +48,10 @@ struct crtfx_ctx {
     float* pre = nullptr;            // pre_frames x H*W*3 float32 pre-warp scratch
     int pre_frames = 1;
     int group_max = 1;               // frames per grouped launch (fills the block slots at small frame sizes)
+    // a frame whose float32 pre-warp image does not fit the Infinity Cache is produced and consumed in BANDS of row segments
+    // (crtfx_set_params plans them; empty = whole frames): band b = source rows [band_src[b], band_src[b + 1]) of k_phosphor_*, then the
+    // output rows [band_row[b], band_row[b + 1]) of k_warp_lean — every tap of those rows lies above the band's last source row
+    std::vector<int> band_src, band_row;
     int group_seg = 128;             // rows per block when a full group is launched (plan_grid)
     int seg_for[4][MAX_GROUP + 1] = {};             // planned rows per block for a (partial) group of g frames, per kernel build (runtime gates / folded / cc / ct)
     // two-stream overlap of k_warp(n) with k_phosphor(n+1): side stream, per-slot events, 2 scratch slots
@@ -63,6 +67,7 @@ struct crtfx_ctx {
     bool force_runtime_flags = false; // CRTFX_OPT_FORCE_RUNTIME_FLAGS: never take a gate-folded instantiation (tests)
     bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
+    int band_mb = 0;                 // CRTFX_OPT_BAND_MB: > 0 = frames whose pre-warp image exceeds that many MiB run band by band (224 keeps a band under the Infinity Cache; tests band small frames with 1); 0 / -1 = whole frames (the default: no gain measured at 8K)
     bool no_plain_warp = false;      // CRTFX_OPT_NO_PLAIN_WARP: k_warp_lean's branch-free build off (tests, A/B)
     bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
@@ -289,7 +294,12 @@ bool use_cc(const crtfx_ctx* c, int R) {
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
-void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
+// [y0, y1) / seg_rows: a band of a frame (crtfx_process_batch) — those rows in segments of seg_rows rows, whatever build the launch lands on;
+// y1 = 0: the whole frame at the planner's segment height for that build.
+void launch_rr_group(crtfx_ctx* c, const KGroup& kg_in, int g, hipStream_t s, int y0 = 0, int y1 = 0, int seg_rows = 0, int prof_frames = -1) {
+    KGroup kg = kg_in;
+    kg.y0 = y1 > 0 ? y0 : 0;
+    kg.y1 = y1 > 0 ? y1 : c->H;
     static rr_launch_fn table[MAX_RADIUS + 1] = {};
     static const bool table_ready = [] {
 #define CRTFX_RR_ENTRY(r) table[r] = rr_launch_##r;
@@ -317,14 +327,14 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg, int g, hipStream_t s) {
     for (int j = 0; j < g && ct; ++j) ct = ((uintptr_t)kg.f[j].in & 3u) == 0;
     int& seg_slot = c->seg_for[ct ? 3 : cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, ct ? 2 : cc ? 1 : 0).seg;   // planned once per (kernel build, group size)
-    const int seg = seg_slot;
+    const int seg = seg_rows > 0 ? seg_rows : seg_slot;
     const int strips = (c->W + TW - 1) / TW;
-    const int segs = (c->H + seg - 1) / seg;
+    const int segs = (kg.y1 - kg.y0 + seg - 1) / seg;
     const int variant = ct ? 6 : cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
     const bool runtime = !folded;
     const size_t lds = ct ? (size_t)ct_lds_words(R) * 4 : cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
                           : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
-    ProfEv pe(c, 0, g);
+    ProfEv pe(c, 0, prof_frames >= 0 ? prof_frames : g);
     table[R](c->kp, kg, seg, dim3(strips, segs, g), lds, s, variant, pe.e0, pe.e1);
 }
 
@@ -367,14 +377,16 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
     constexpr bool SEQ = BLEND == CRTFX_BLEND_RENDER || WL_SEQ > 1;
     const int nseq = BLEND == CRTFX_BLEND_RENDER ? ntot : min(WL_SEQ, ntot);
     grid.x = (grid.x + WX - 1) / WX;
-    grid.y = (c->H + (4 / WX) * rows - 1) / ((4 / WX) * rows);
+    grid.y = ((int)grid.y + (4 / WX) * rows - 1) / ((4 / WX) * rows);      // the caller's grid.y = the ROWS to cover (a band, or the frame)
     grid.z = (ntot + nseq - 1) / nseq;
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
     // the headline shape — unblended uint8 frames, none of which keeps a float state, rows of whole dwords — on the branch-free build
-    if constexpr (BLEND == CRTFX_BLEND_NONE && PIX == CRTFX_PIX_U8 && !SEQ) {
-        bool plain = rows == 4 && (c->W & 3) == 0 && !c->no_plain_warp;
-        for (int j = 0; j < ntot && plain; ++j) plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr;
+    if constexpr (BLEND == CRTFX_BLEND_NONE && !SEQ) {
+        // rows of whole dwords: uint8 frames with W % 4 == 0; half frames with W % 2 == 0 on a dword-aligned base
+        bool plain = rows == 4 && !c->no_plain_warp && (PIX == CRTFX_PIX_F16 ? (c->W & 1) == 0 && (size_t)c->H * c->W * 6 < ((size_t)1 << 31) : (c->W & 3) == 0);
+        for (int j = 0; j < ntot && plain; ++j)
+            plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr && (PIX != CRTFX_PIX_F16 || ((uintptr_t)wg.o[j].out_u8 & 3u) == 0);
         if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
     }
     if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
@@ -387,10 +399,8 @@ void launch_warp_lean(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, h
     else launch_warp_lean2<PROMOTE, BLEND, CRTFX_PIX_U8>(c, wg, grid, ntot, s, e0, e1);
 }
 
-// chain: the g frames are consecutive frames of ONE persistence recurrence (frame j + 1 blends with frame j's state); else independent frames.
-void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity, hipStream_t s, bool chain = false) {
-    dim3 grid((c->W + TW - 1) / TW, (c->H + 3) / 4, g);
-    // plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend)
+// plain render frames (no glitch band, overlay or float output; every frame of the group with the same blend) take k_warp_lean
+bool warp_lean_ok(const crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity) {
     bool lean = !c->force_generic && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);      // k_warp_lean reads the image through a 32-bit buffer resource
     if (identity && !(wg.o[0].blend == CRTFX_BLEND_RENDER && c->pix_fmt == CRTFX_PIX_U8)) lean = false;      // commit-only lean build: render blend, uint8 frames
     for (int j = 0; j < g && lean; ++j) {
@@ -398,13 +408,24 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
         lean = !o.overlay_after && !o.glitch_offs && !o.out_f32 && o.blend == wg.o[0].blend &&
                (o.blend == CRTFX_BLEND_NONE || o.blend == CRTFX_BLEND_RENDER);
     }
+    return lean;
+}
+
+// chain: the g frames are consecutive frames of ONE persistence recurrence (frame j + 1 blends with frame j's state); else independent frames.
+// [y0, y1): the output rows of a banded launch (lean, unblended, warp on: the caller has checked warp_lean_ok); y1 < 0 = the whole frame.
+void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg_in, int g, bool identity, hipStream_t s, bool chain = false, int y0 = 0, int y1 = -1, int prof_frames = -1) {
+    KWarpGroup wg = wg_in;
+    wg.y0 = y0;
+    const int rows_out = (y1 < 0 ? c->H : y1) - y0;
+    dim3 grid((c->W + TW - 1) / TW, rows_out, g);      // y: rows here, tiles below
+    const bool lean = warp_lean_ok(c, wg, g, identity);
     if (lean) {
-        ProfEv pe(c, 1, g);
+        ProfEv pe(c, 1, prof_frames >= 0 ? prof_frames : g);
         const bool prom = (c->kp.flags & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0;
         const bool rend = wg.o[0].blend == CRTFX_BLEND_RENDER;
         if (rend) grid.z = 1;       // the g frames of a persistence chain: one after the other inside each thread, the state in registers
         if (identity) {             // no warp behind the Gaussian chain: the blend and the commit only
-            grid.y = (c->H + 7) / 8;
+            grid.y = (rows_out + 7) / 8;
             if (prom) { CRTFX_LAUNCH((k_warp_lean<true, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
             else { CRTFX_LAUNCH((k_warp_lean<false, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
             return;
@@ -413,6 +434,7 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg, int g, bool identity,
         else { if (rend) launch_warp_lean<false, CRTFX_BLEND_RENDER>(c, wg, grid, g, s, pe.e0, pe.e1); else launch_warp_lean<false, CRTFX_BLEND_NONE>(c, wg, grid, g, s, pe.e0, pe.e1); }
         return;
     }
+    grid.y = (rows_out + 3) / 4;    // the general kernel: 64 x 4 tiles (whole frames only)
     if (chain && g > 1) {           // a persistence chain on the general kernel: its frames commit strictly in order (ref:1081-1105)
         for (int j = 0; j < g; ++j) {
             KWarpGroup one{};
@@ -776,6 +798,56 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
             HIP_TRY(c, hipMalloc((void**)&c->pre, (size_t)need * H * W * 3 * sizeof(float)));
             c->pre_frames = need;
         }
+        // Bands.  One frame's float32 pre-warp image larger than the Infinity Cache (8K: 398 MB) used to be written whole and read back
+        // from HBM; split into bands of row segments of <= 224 MB each, k_phosphor(band b) is followed at once by the k_warp_lean rows
+        // that only need source rows above the band's end.  The barrel map is monotone in y and, for a fixed row, extreme at the frame's
+        // centre column or its edges, so the last source row an output row touches is found from three columns of the host's own axis
+        // tables with the kernels' float32 arithmetic (+ 1 for the lower tap, + 1 row of margin).
+        c->band_src.clear(); c->band_row.clear();
+        const size_t frame_scratch = (size_t)H * W * 3 * sizeof(float);
+        const size_t band_bytes = (size_t)(c->band_mb > 0 ? c->band_mb : 224) << 20;
+        // OFF unless asked for (BAND_MB > 0): measured on 8K float16 frames (profiles/r04_8k_bands.txt), two bands of 199 MB leave k_phosphor
+        // where it was (2 x 139.5 against 278 us per frame) and take k_warp_lean from 141 to 137 us — the 8K warp is bound by its 6-byte
+        // output pixels and its taps' instruction count, not by Infinity-Cache misses; four bands are 5 % slower
+        if ((k.flags & CRTFX_F_WARP) && gp.g == 1 && frame_scratch > band_bytes && c->band_mb > 0 && p->warp_xhat && p->warp_yhat &&
+            (fl & CRTFX_F_BLOOM) && !fastb && !split && frame_scratch < ((size_t)1 << 31)) {
+            const int nb = (int)((frame_scratch + band_bytes - 1) / band_bytes);
+            const int hband = (((H + nb - 1) / nb) + NB - 1) / NB * NB;
+            // the launch shape of ONE band: the planner's for a frame of the band's height (its short last segment frees block slots for
+            // the overflow of a grid slightly larger than one resident round, as in the 4K two-frame group)
+            if (!(c->opt_seg_rows >= NB)) gp.seg = plan_grid(hband, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, 1, cc_build).seg;
+            std::vector<int> need(H);
+            const float* xh = static_cast<const float*>(p->warp_xhat);
+            const float* yh = static_cast<const float*>(p->warp_yhat);
+            const int xs[4] = {0, W - 1, (W - 1) / 2, W / 2};
+            for (int y = 0; y < H; ++y) {
+                int m = -(1 << 30);
+                for (int xi = 0; xi < 4; ++xi) {
+                    const float xv = xh[xs[xi]], yv = yh[y];
+                    const float r2 = xv * xv + yv * yv;
+                    const float factor = 1.0f + k.warp_k * r2;
+                    const float my = (yv * factor) * k.cy + k.cy;
+                    const int sy = (int)rintf(my * 32.0f);
+                    const int iy = sy >> 5;
+                    if (iy > m) m = iy;
+                }
+                need[y] = m + 2;
+            }
+            c->band_src.push_back(0); c->band_row.push_back(0);
+            for (int b = 1; b <= nb; ++b) {
+                const int src_end = b * hband < H ? b * hband : H;      // source rows [0, src_end) exist once band b - 1 has been written
+                int row = H;
+                if (src_end < H) {
+                    row = c->band_row.back();
+                    while (row < H && need[row] < src_end) ++row;
+                    row &= ~7;                                   // whole 8-row tiles
+                    if (row < c->band_row.back()) row = c->band_row.back();
+                }
+                c->band_src.push_back(src_end); c->band_row.push_back(row);
+                if (src_end >= H) break;
+            }
+            if (c->band_src.size() < 3) { c->band_src.clear(); c->band_row.clear(); }      // one band = the whole frame
+        }
         c->group_max = gp.g;
         c->group_seg = gp.seg;
         if (c->debug_plan) fprintf(stderr, "[crtfx] %dx%d R=%d: %d frame(s) per grid, %d rows per block%s\n", W, H, R, gp.g, gp.seg, cc_build == 2 ? " (k_phosphor_ct)" : cc_build ? " (k_phosphor_cc)" : "");
@@ -939,9 +1011,24 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 // and a 42-VGPR warp wave fits beside four 115-VGPR phosphor waves per SIMD).  Two scratch slots.
                 hipStream_t sw = ovl ? c->side : s;
                 if (ovl && c->ev_k2_pending[slot]) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_k2[slot], 0));   // slot free again
-                launch_rr_group(c, kg, g, s);
+                bool banded = false;
+                if (two && !blend_on && warp && g == 1 && !ovl && c->band_src.size() >= 3) {
+                    // a frame larger than the Infinity Cache, band by band: k_phosphor over the band's row segments, then the output rows
+                    // whose taps it completes (planned in crtfx_set_params); the launches of a frame are timed as ONE frame
+                    KWarpGroup wg{};
+                    wg.pre[0] = c->pre + (size_t)slot * c->group_max * frame_elems; wg.o[0] = final_out(i);
+                    if (warp_lean_ok(c, wg, 1, false)) {
+                        banded = true;
+                        for (size_t b = 0; b + 1 < c->band_src.size(); ++b) {
+                            launch_rr_group(c, kg, 1, s, c->band_src[b], c->band_src[b + 1], c->group_seg, b == 0 ? 1 : 0);
+                            if (c->band_row[b + 1] > c->band_row[b])
+                                launch_warp_group(c, wg, 1, false, s, false, c->band_row[b], c->band_row[b + 1], b == 0 ? 1 : 0);
+                        }
+                    }
+                }
+                if (!banded) launch_rr_group(c, kg, g, s);
                 if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k1[slot], s)); HIP_TRY(c, hipStreamWaitEvent(sw, c->ev_k1[slot], 0)); }
-                if (two) {
+                if (two && !banded) {
                     const float* pre0 = c->pre + (size_t)slot * c->group_max * frame_elems;
                     if (!blend_on) {
                         KWarpGroup wg{};
@@ -1126,6 +1213,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
     case CRTFX_OPT_NO_CT: c->no_ct = value != 0; break;
     case CRTFX_OPT_NO_PLAIN_WARP: c->no_plain_warp = value != 0; break;
+    case CRTFX_OPT_BAND_MB: if (value < -1 || value > 4096) return fail(c, CRTFX_E_INVALID, "band_mb %d outside -1..4096", value); c->band_mb = value; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
     case CRTFX_OPT_SPLIT_SRC_PLANE: c->split_src_plane = value != 0; break;
     case CRTFX_OPT_SPLIT_FROM: if (value < 0) return fail(c, CRTFX_E_INVALID, "split_from %d < 0", value); c->split_from = value; break;

@@ -89,8 +89,11 @@ struct KOut {
 #define CRTFX_MAX_GROUP 8
 #endif
 constexpr int MAX_GROUP = CRTFX_MAX_GROUP;
-struct KGroup { KFrame f[MAX_GROUP]; KOut o[MAX_GROUP]; };
-struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; };
+// y0, y1 / y0: a launch may cover a BAND of a frame only — the rows [y0, y1) of k_phosphor_* (cut into row segments from y0), output rows
+// from y0 of k_warp_lean — so that a frame whose float32 pre-warp image is larger than the Infinity Cache (8K: 398 MB) can be produced
+// and consumed band by band (crtfx_process_batch); the host sets y0 = 0, y1 = H for whole-frame launches.
+struct KGroup { KFrame f[MAX_GROUP]; KOut o[MAX_GROUP]; int y0, y1; };
+struct KWarpGroup { const float* pre[MAX_GROUP]; KOut o[MAX_GROUP]; int y0; };
 
 // internal gate (set by crtfx_set_params, never by callers): the analytic vignette gain lies in [0,1]
 // (0 <= strength <= 1), so clip(x * gain) of an x in [0,1] is the identity and is skipped.
@@ -437,6 +440,24 @@ __device__ __forceinline__ void store_row_f16(uint8_t* __restrict__ out, size_t 
     if (lane < valid_px) {
         uint16_t* p = reinterpret_cast<uint16_t*>(out) + (row_px0 + (size_t)lane) * 3;
         p[0] = (uint16_t)pk.lo; p[1] = (uint16_t)(pk.lo >> 16); p[2] = (uint16_t)pk.hi;
+    }
+}
+// The same row segment of half pixels as whole dwords through a buffer resource (rows of an even number of pixels: the segment's 6-byte
+// pixels then fill dwords exactly).  Lane l holds pixel l as lo = r | g << 16, hi = b; dword d of the segment is
+//   d = 3m: lo[2m]      d = 3m + 1: hi[2m] | (lo[2m+1] & 0xffff) << 16      d = 3m + 2: lo[2m+1] >> 16 | hi[2m+1] << 16
+// so the wave stores dwords 0..63 with one instruction and 64..95 with a second (three cross-lane reads each) instead of three
+// 2-byte stores per lane at a 6-byte stride.  Dwords past the segment's end get an out-of-range offset: dropped by the hardware.
+template <int AUX = 0>
+__device__ __forceinline__ void store_row_f16_buf(__amdgpu_buffer_rsrc_t rs, uint32_t row_byte0, int lane, int valid_px, PackedPix pk) {
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int d = part * 64 + lane;
+        const int m = d / 3, t = d - 3 * m;
+        const int sa = (2 * m + (t == 2 ? 1 : 0)) & 63, sb = (2 * m + 1) & 63;
+        const uint32_t x = __shfl(pk.lo, sa), y = __shfl(pk.hi, sa), z = __shfl(pk.lo, sb);
+        const uint32_t dw = t == 0 ? x : (t == 1 ? ((y & 0xFFFFu) | (z << 16)) : ((x >> 16) | (y << 16)));
+        const uint32_t off = (d < 96 && 4 * d + 4 <= valid_px * 6) ? row_byte0 + 4u * (uint32_t)d : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b32(dw, rs, off, 0, AUX);
     }
 }
 __device__ __forceinline__ void store_row_pix(const KOut& O, size_t row_px0, int lane, int valid_px, PackedPix pk) {

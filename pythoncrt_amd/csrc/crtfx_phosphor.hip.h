@@ -276,9 +276,9 @@ __global__ __launch_bounds__(RR_THREADS, rr_min_waves(RT, SF != 0xFFFFFFFFu)) vo
     const int wave = tid >> 6;
     const int H = P.H, W = P.W;
     const int x0 = blockIdx.x * TW;
-    const int y_begin = blockIdx.y * seg_rows;
-    const int y_end = min(H, y_begin + seg_rows);
-    if (y_begin >= H) return;
+    const int y_begin = G.y0 + (int)blockIdx.y * seg_rows;
+    const int y_end = min(G.y1, y_begin + seg_rows);
+    if (y_begin >= G.y1) return;
     const uint32_t fl = P.flags;
 
     if ((fl & CRTFX_F_TRIAD) && (fl & CRTFX_F_TRIAD_LUT)) {
@@ -677,9 +677,9 @@ __global__ __launch_bounds__(RR_THREADS, cc_min_waves(RT)) void k_phosphor_cc(KP
     const int wave = tid >> 6;
     const int H = P.H, W = P.W;
     const int x0 = blockIdx.x * TW;
-    const int y_begin = blockIdx.y * seg_rows;
-    const int y_end = min(H, y_begin + seg_rows);
-    if (y_begin >= H) return;
+    const int y_begin = G.y0 + (int)blockIdx.y * seg_rows;
+    const int y_end = min(G.y1, y_begin + seg_rows);
+    if (y_begin >= G.y1) return;
 
     for (int i = tid; i < LUT_N; i += RR_THREADS) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
     if constexpr (NLUT) { if (tid < 256) nlut[tid] = norm_u8((uint32_t)tid); }

@@ -116,9 +116,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     const int wave = tid >> 6;
     const int H = P.H, W = P.W;
     const int x0 = blockIdx.x * TW;
-    const int y_begin = blockIdx.y * seg_rows;
-    const int y_end = min(H, y_begin + seg_rows);
-    if (y_begin >= H) return;
+    const int y_begin = G.y0 + (int)blockIdx.y * seg_rows;
+    const int y_end = min(G.y1, y_begin + seg_rows);
+    if (y_begin >= G.y1) return;
     const uint32_t row_elems = (uint32_t)W * 3u;
 
     // ---- which form this strip runs ---------------------------------------------------------------------------------------------

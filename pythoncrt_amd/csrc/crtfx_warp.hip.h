@@ -172,7 +172,8 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 // issue slots (profiles/r03_ct_ablation.txt, E).
 // IDENT: no warp — the commit alone (a persistence blend behind the Gaussian chain with warp off): the tap is the pixel itself.
 // WX: waves side by side in a block's tile — (64 * WX) pixels x (4 / WX * ROWS) rows, a thread's rows 4 / WX apart.
-// PLAIN: what the launcher has checked for the whole group — uint8 frames out (never null), no state to keep, W % 4 == 0 — so the body has no
+// PLAIN: what the launcher has checked for the whole group — frames out (never null; uint8 with W % 4 == 0, or half with W % 2 == 0 and a
+// dword-aligned base: whole dwords per row segment), no state to keep — so the body has no
 // branch at all: a row past the bottom redoes the last one and its dword stores land beyond the output buffer's range (dropped by the
 // hardware), and the sixteen tap loads of a thread issue before the first interpolation.
 #ifndef WARP_PLAIN_WAVES
@@ -180,7 +181,7 @@ __device__ __forceinline__ void warp_combine(const WarpTaps& t, T& o0, T& o1, T&
 #endif
 template <bool PROMOTE, int BLEND, int PIX, int ROWS, bool IDENT = false, int WX = 1, bool SEQ = true, bool PLAIN = false>
 __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_lean(KParams P, KWarpGroup G, int nseq, int ntot) {
-    static_assert(!PLAIN || (BLEND == CRTFX_BLEND_NONE && PIX == CRTFX_PIX_U8 && !IDENT && !SEQ), "PLAIN: unblended uint8 frames behind a warp");
+    static_assert(!PLAIN || (BLEND == CRTFX_BLEND_NONE && !IDENT && !SEQ), "PLAIN: unblended frames behind a warp");
     constexpr int WY = 4 / WX;
     using T = typename std::conditional<PROMOTE, double, float>::type;
     const int z0 = (int)blockIdx.z * nseq;                   // BLEND_RENDER: one z slice
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int x0 = (blockIdx.x * WX + wv % WX) * TW;
-    const int ybase = blockIdx.y * (WY * ROWS) + wv / WX;
+    const int ybase = G.y0 + blockIdx.y * (WY * ROWS) + wv / WX;
     if (ybase >= P.H || x0 >= P.W) return;
     // (s_setprio 1 / 3 once the taps have been requested — a wave whose taps have arrived drains ahead of the waves still
     // issuing loads — measured slower: 59.2 / 60.8 vs 56.6 us per 2-frame 4K launch.)
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
         const float* __restrict__ pre = G.pre[z0 + jf];      // wave-uniform index: scalar loads
         const KOut O = G.o[z0 + jf];
         const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 12u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, O.out_u8 ? (int)((uint32_t)P.H * (uint32_t)P.W * 3u) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, O.out_u8 ? (int)((uint32_t)P.H * (uint32_t)P.W * (PIX == CRTFX_PIX_F16 ? 6u : 3u)) : 0, 0x00020000);
         // the state is stored behind this frame when nobody keeps it in registers for the next one: the group's last frame,
         // or a frame whose record names its own state buffer
         const bool keep_state = BLEND != CRTFX_BLEND_RENDER || jf == nf - 1 || G.o[z0 + jf + 1].state != O.state;
@@ -260,8 +261,12 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
             const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2;
             if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = F3{f0, f1, f2};
             if constexpr (PLAIN) {
-                // row y >= H: ((y * W + x0) * 3 >= H * W * 3, the buffer's size: every dword of the row is dropped
-                store_row_u8_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 3u) + (uint32_t)x0 * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), true);
+                // row y >= H: its byte offset is >= the buffer's size: every dword of the row is dropped
+                if constexpr (PIX == CRTFX_PIX_F16)
+                    store_row_f16_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 6u) + (uint32_t)x0 * 6u, lane, min(64, P.W - x0),
+                                         PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
+                else
+                    store_row_u8_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 3u) + (uint32_t)x0 * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), true);
                 continue;
             }
             if (O.state && live && keep_state) *reinterpret_cast<F3*>(O.state + pix * 3u) = F3{f0, f1, f2};

@@ -397,7 +397,7 @@ def test_option_values_are_checked(pc, monkeypatch):
     from pythoncrt_amd import _lib, effects
     frame = make_frame(48, 64)
     a = [frame, 0.6, None, 2.2, False, 1, 1.2, 0.25, 0.0, 0.0, None, 2.0, 0.0, False, 1, 0, 0.0]
-    for bad, pat in (({"WARP_ROWS": 3}, "warp rows"), ({"WARP_ROWS": -1}, "warp rows"), ({"GROUP": 99}, "."), ({"POINT_TILES": 17}, ".")):
+    for bad, pat in (({"WARP_ROWS": 3}, "warp rows"), ({"WARP_ROWS": -1}, "warp rows"), ({"GROUP": 99}, "."), ({"POINT_TILES": 17}, "."), ({"BAND_MB": -2}, "band_mb")):
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(bad))
         effects._tls.engines = {}
         with pytest.raises(_lib.CrtfxError, match=pat):
@@ -798,6 +798,36 @@ def test_fp16_frames(pc, cfg):
     exp16 = np.abs(so.astype(np.float32) * np.float32(255.0)).astype(np.float16)
     assert np.abs(ug.astype(np.float32) - exp16.astype(np.float32)).max() <= 0.125      # one half ulp at 128..255
     assert (ug != exp16).mean() < 5e-3          # half is 32x finer than uint8 around 200: more last-bit flips per float ulp
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_banded_frames_equal_whole_frames(pc, half, monkeypatch):
+    """A frame whose float32 pre-warp image does not fit the Infinity Cache (8K: 398 MB) runs as bands of row segments — k_phosphor over a
+    band, then at once the k_warp_lean rows whose taps the band completes (crtfx_set_params plans the split from the barrel map).  BAND_MB = 1
+    bands these small frames into 2 - 4 pieces: the frames must equal the whole-frame launches bit for bit, for barrel and pincushion maps,
+    a strong warp (rows that need source rows far below them), both pixel formats, and frames too small to band."""
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = 3
+    for (h, w, warp, sigma) in [(520, 448, 0.15, 3.0), (300, 704, -0.4, 1.2), (416, 512, 0.9, 2.0), (1000, 128, 0.15, 4.4), (64, 128, 0.15, 3.0)]:
+        if half:
+            frames = torch.from_numpy(np.stack([f16_frame(h, w, 40 + i) for i in range(n)])).to(dev)
+        else:
+            frames = torch.from_numpy(np.stack([make_frame(h, w, seed=40 + i, kind="grad") for i in range(n)])).to(dev)
+        rs = RenderSettings(fast_bloom=False, bloom_sigma=sigma, pixel_size=1, persistence=0.0, warp_strength=warp)
+        outs = {}
+        for name, opts in (("whole", {"GROUP": 1, "BAND_MB": -1}), ("banded", {"GROUP": 1, "BAND_MB": 1}), ("banded_rows2", {"GROUP": 1, "BAND_MB": 1, "WARP_ROWS": 2}),
+                           ("banded_seg", {"GROUP": 1, "BAND_MB": 1, "SEG_ROWS": 48}),
+                           ("general_warp", {"GROUP": 1, "BAND_MB": -1, "NO_PLAIN_WARP": 1})):      # k_warp_lean's general build (per-lane 2-byte stores for half frames)
+            monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+            effects._tls.engines = {}
+            pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=11, dtype=frames.dtype)
+            out, _ = pipe.run(frames, first_index=5)
+            outs[name] = out.cpu().numpy()
+        for name in ("banded", "banded_rows2", "banded_seg", "general_warp"):
+            assert np.array_equal(outs["whole"].view(np.uint8), outs[name].view(np.uint8)), (h, w, warp, name)
+    effects._tls.engines = {}
 
 
 def test_frames_that_do_not_start_on_a_dword(pc):
