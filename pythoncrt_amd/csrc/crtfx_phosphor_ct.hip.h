@@ -275,15 +275,9 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             // pre-warp image out through a buffer resource over this block's row segment: one SGPR descriptor + a 32-bit byte
             // offset per store, and an offset outside the segment — rows above / below it (the first trips' and the last trip's
             // garbage rows), lanes right of the frame (offset pinned out of range) — is DROPPED by the hardware's range check
-#ifdef CRTFX_PRE16      // timing + accuracy experiment (profiles/r04_pre16.txt): the pre-warp image as 8-byte pixels of four unorm16 (r, g, b, unused)
-            const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(O.pre) + (size_t)y_begin * (size_t)W * 8u, 0,
-                                                                                      (int)((uint32_t)(y_end - y_begin) * (uint32_t)W * 8u), 0x00020000);
-            const uint32_t row_b = fin ? (uint32_t)W * 8u : 0u;
-#else
             const __amdgpu_buffer_rsrc_t pre_rsrc = __builtin_amdgcn_make_buffer_rsrc(O.pre + (size_t)y_begin * (size_t)W * 3u, 0,
                                                                                       (int)((uint32_t)(y_end - y_begin) * (uint32_t)W * 12u), 0x00020000);
             const uint32_t row_b = fin ? (uint32_t)W * 12u : 0u;                     // bytes per pre-warp image row (this lane's stride)
-#endif
             // the frame's scanline row gains through a buffer resource too: rows outside the frame read as 0 (never consumed)
             const __amdgpu_buffer_rsrc_t scan_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F.scan_row), 0, H * 4, 0x00020000);
             // this float's centre byte inside a ring row: FAST — its byte of the frame-row window (a2: R from column x - d, B from
@@ -386,11 +380,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             // output rows yb + j = hb - NB - R + j from ring rows (n * NB - NB - (R - RSH) + j) & 31
             uint32_t crow0 = 0u, c2row0 = (uint32_t)((-NB - (R - RSH)) * TW * 4) & RING_MASK;
             int hb = y_begin - R;
-#ifdef CRTFX_PRE16
-            uint32_t off0 = fin ? (uint32_t)(-2 * R - NB) * row_b + (uint32_t)(x0 + fcol) * 8u + (uint32_t)fch * 2u : 0xFFFFFF00u;
-#else
             uint32_t off0 = fin ? (uint32_t)(-2 * R - NB) * row_b + ((uint32_t)x0 * 3u + (uint32_t)f) * 4u : 0xFFFFFF00u;      // (row hb - NB - R of the segment, float f), modulo 2^32 while that row is above it
-#endif
             for (int n = 0; n < n_iter; ++n, hb += NB, off0 += (uint32_t)NB * row_b, crow0 = (crow0 + NB * TW * 4) & RING_MASK,
                                             c2row0 = (c2row0 + NB * TW * 4) & RING_MASK) {
                 // ---- phase 1 ----
@@ -444,12 +434,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     uint32_t boff = off0;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-#ifdef CRTFX_PRE16
-                        const auto q2 = __builtin_amdgcn_cvt_pknorm_u16(v[j], 0.0f);
-                        __builtin_amdgcn_raw_buffer_store_b16((uint16_t)q2[0], pre_rsrc, boff, 0, 0);
-#else
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), pre_rsrc, boff, 0, 0);
-#endif
                         boff += row_b;
                     }
                 }
@@ -479,11 +464,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                     const float r = clip01(v[j] * __uint_as_float(__builtin_amdgcn_readlane(slv, j)));
                     double d = (double)r * gvig[j * TW + fcol];
                     d = clip01(d + (double)gt[j * TW + fcol]);
-#ifdef CRTFX_PRE16
-                    if (y >= y_begin && y < y_end && fin) reinterpret_cast<uint16_t*>(O.pre)[((uint32_t)y * (uint32_t)W + (uint32_t)(x0 + fcol)) * 4u + (uint32_t)fch] = (uint16_t)__builtin_amdgcn_cvt_pknorm_u16((float)d, 0.0f)[0];
-#else
                     if (y >= y_begin && y < y_end && fin) O.pre[((uint32_t)y * (uint32_t)W + (uint32_t)x0) * 3u + (uint32_t)f] = (float)d;
-#endif
                 }
             }
         };

@@ -218,9 +218,6 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
         // 24-bit multiplies (|iyc| <= 32767, W * 12 < 2^19, |ixc| <= 32767): v_mad_i32_i24 at half the cost of the 64-bit multiply-add hipcc forms for the 32-bit product
         off_a[r] = (uint32_t)(__mul24(iyc, P.W * 12) + __mul24(ixc, 12));        // a negative offset (rows -2, -1) wraps far past the buffer's end
         off_b[r] = off_a[r] + (uint32_t)P.W * 12u;
-#ifdef CRTFX_PRE16
-        if constexpr (PLAIN) { off_a[r] = (uint32_t)(__mul24(iyc, P.W * 8) + __mul24(ixc, 8)); off_b[r] = off_a[r] + (uint32_t)P.W * 8u; }
-#endif
     }
     F3 st[ROWS];
     if constexpr (BLEND == CRTFX_BLEND_RENDER) {
@@ -240,24 +237,6 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
         // or a frame whose record names its own state buffer
         const bool keep_state = BLEND != CRTFX_BLEND_RENDER || jf == nf - 1 || G.o[z0 + jf + 1].state != O.state;
         WarpTaps taps[ROWS];
-#ifdef CRTFX_PRE16
-        if constexpr (PLAIN) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t p16 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 8u), 0x00020000);
-            u32x4 ab[ROWS], cd[ROWS];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) { ab[r] = __builtin_amdgcn_raw_buffer_load_b128(p16, off_a[r], 0, 0); cd[r] = __builtin_amdgcn_raw_buffer_load_b128(p16, off_b[r], 0, 0); }
-            const float sc = 1.0f / 65535.0f;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                taps[r].u00 = u00[r]; taps[r].u01 = u01[r]; taps[r].u10 = u10[r]; taps[r].u11 = u11[r];
-                taps[r].A = F3{(float)(ab[r][0] & 0xFFFFu) * sc, (float)(ab[r][0] >> 16) * sc, (float)(ab[r][1] & 0xFFFFu) * sc};
-                taps[r].B = F3{(float)(ab[r][2] & 0xFFFFu) * sc, (float)(ab[r][2] >> 16) * sc, (float)(ab[r][3] & 0xFFFFu) * sc};
-                taps[r].C = F3{(float)(cd[r][0] & 0xFFFFu) * sc, (float)(cd[r][0] >> 16) * sc, (float)(cd[r][1] & 0xFFFFu) * sc};
-                taps[r].D = F3{(float)(cd[r][2] & 0xFFFFu) * sc, (float)(cd[r][2] >> 16) * sc, (float)(cd[r][3] & 0xFFFFu) * sc};
-            }
-        } else
-#endif
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             taps[r].u00 = u00[r]; taps[r].u01 = u01[r]; taps[r].u10 = u10[r]; taps[r].u11 = u11[r];
