@@ -11,7 +11,12 @@ X="$@"
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-PB="--steps 2 --warmup 1 --batch 8 --repeats 0 --cpu-frames 0 --no-profile"      # PMC passes: few launches, no event timing
+# PMC passes: few steps, no event timing — but a batch far beyond the 256 MB Infinity Cache (default 256 frames: 6.4 GB in + 6.4 GB out at 4K), so
+# that the input and output frames come from / go to HBM as in the bench's 1920-frame steps (rounds 1-3 measured at batch 8, where everything
+# stayed cache-resident).  The batch is recorded in gpurun_out/<tag>_pmc_batch.txt for summarise_profiles.py.
+PMC_BATCH=${PMC_BATCH:-256}
+echo $PMC_BATCH > $OUT/${TAG}_pmc_batch.txt
+PB="--steps 2 --warmup 1 --batch $PMC_BATCH --repeats 0 --cpu-frames 0 --no-profile"
 timeout -k 10 300 python3 $R/bench.py $X > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $R/bench.py $X --steps 10 --repeats 0 --cpu-frames 0 > $OUT/${TAG}_trace.log 2>&1
 rm -f $OUT/${TAG}_trace/*/*kernel_trace.csv      # the per-dispatch trace (tens of MB) is not needed: the stats CSV is what gets committed

@@ -25,6 +25,10 @@ def counters(part):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
+try:
+    pmc_batch = int(open(f"gpurun_out/{tag}_pmc_batch.txt").read().strip())      # frames per step of the PMC passes (tools/collect_profiles.sh)
+except (OSError, ValueError):
+    pmc_batch = 8
 ks = newest(glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True))
 if ks:
     rows = [r for r in csv.reader(open(ks[0]))]
@@ -70,7 +74,7 @@ raw = sum((d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls
 cor = sum((d.get("FETCH_SIZE", 0) * fetch_fix[cls(k)] + d.get("WRITE_SIZE", 0)) * 1024 / fpl.get(cls(k), 1.0) for k, d in pmc.items())
 tj = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
 tj = {k: v for k, v in tj.items() if isinstance(v, dict) and "source_hash" in v}      # drop round-1 style entries
-tj[cfg] = {"bytes_per_frame_as_reported": int(raw), "bytes_per_frame_corrected": int(cor), "source_hash": src, "tag": tag, "batch": 8,
+tj[cfg] = {"bytes_per_frame_as_reported": int(raw), "bytes_per_frame_corrected": int(cor), "source_hash": src, "tag": tag, "batch": pmc_batch,
            "correction": {"FETCH_SIZE multiplier by kernel class (1 / calibration ratio)": fetch_fix, "WRITE_SIZE": "exact",
                           "calibration": f"profiles/{tag}_fetch_calibration.txt"},
            "per_launch_as_reported": {k: dict({c: int(v * 1024) for c, v in d.items() if c in ("FETCH_SIZE", "WRITE_SIZE")},
