@@ -231,8 +231,6 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *                        256 MiB Infinity Cache) runs as bands of rows, each k_phosphor band followed at once by the k_warp_lean rows
  *                        whose taps it completes; 0 / -1 (default) = whole-frame launches — at 8K the bands measured +0.5 %
  *                        (profiles/r04_8k_bands.txt), so they stay an A/B switch; tests band small frames with 1
- *   NO_WARP_STAGE        unblended uint8 frames behind a gentle warp stay on k_warp_lean's gather instead of k_warp_stage (source rows staged
- *                        through LDS) (A/B)
  *   POINT_TILES          rows per k_point block (1..16; 0 = default)
  *   OVERLAP              run k_warp(n) on a side stream beside k_phosphor(n+1) (measured slower; kept for A/B)
  *   SPLIT_FROM           Gaussian-bloom radii >= this run the split path (blur kernels of any radius + the pointwise chain)
@@ -242,7 +240,7 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
 typedef enum crtfx_option {
     CRTFX_OPT_FORCE_GENERIC = 1, CRTFX_OPT_FORCE_RUNTIME_FLAGS = 2, CRTFX_OPT_NO_CC = 3, CRTFX_OPT_GROUP = 4, CRTFX_OPT_SEG_ROWS = 5,
     CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9, CRTFX_OPT_FORCE_CC = 10,
-    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12, CRTFX_OPT_NO_CT = 13, CRTFX_OPT_NO_PLAIN_WARP = 14, CRTFX_OPT_BAND_MB = 15, CRTFX_OPT_NO_WARP_STAGE = 16
+    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12, CRTFX_OPT_NO_CT = 13, CRTFX_OPT_NO_PLAIN_WARP = 14, CRTFX_OPT_BAND_MB = 15
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 

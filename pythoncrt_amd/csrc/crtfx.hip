@@ -68,8 +68,6 @@ struct crtfx_ctx {
     bool force_cc = false;           // CRTFX_OPT_FORCE_CC: k_phosphor_cc for every radius and pixel format it is built for (tests)
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
     int band_mb = 0;                 // CRTFX_OPT_BAND_MB: > 0 = frames whose pre-warp image exceeds that many MiB run band by band (224 keeps a band under the Infinity Cache; tests band small frames with 1); 0 / -1 = whole frames (the default: no gain measured at 8K)
-    bool no_warp_stage = false;      // CRTFX_OPT_NO_WARP_STAGE: the LDS-staged warp build off (tests, A/B)
-    bool warp_stage_ok = false;      // crtfx_set_params: >= 80 % of the 32 x 8 output tiles' source windows fit k_warp_stage's LDS tile
     bool no_plain_warp = false;      // CRTFX_OPT_NO_PLAIN_WARP: k_warp_lean's branch-free build off (tests, A/B)
     bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
@@ -389,17 +387,6 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
         bool plain = rows == 4 && !c->no_plain_warp && (PIX == CRTFX_PIX_F16 ? (c->W & 1) == 0 && (size_t)c->H * c->W * 6 < ((size_t)1 << 31) : (c->W & 3) == 0);
         for (int j = 0; j < ntot && plain; ++j)
             plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr && (PIX != CRTFX_PIX_F16 || ((uintptr_t)wg.o[j].out_u8 & 3u) == 0);
-        if constexpr (PIX == CRTFX_PIX_U8) {
-            // ... and, where the barrel map is gentle enough for a wave's source window to fit its LDS tile (crtfx_set_params counts the tiles),
-            // on the build that stages whole source rows through LDS instead of gathering 12-byte taps (k_warp_stage)
-            if (plain && c->warp_stage_ok && !c->no_warp_stage && c->warp_rows == 0) {
-                const int rows_out = (int)grid.y * ((4 / WX) * rows);      // grid.y was converted to tiles above: whole tiles of the rows to cover
-                (void)rows_out;
-                dim3 gs((c->W + 127) / 128, grid.y, ntot);                 // 128 x 8 pixels per block = the same tile rows as the gather build's
-                CRTFX_LAUNCH((k_warp_stage<PROMOTE>), gs, dim3(256), 0, s, e0, e1, c->kp, wg);
-                return;
-            }
-        }
         if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
     }
     if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
@@ -816,37 +803,6 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         // that only need source rows above the band's end.  The barrel map is monotone in y and, for a fixed row, extreme at the frame's
         // centre column or its edges, so the last source row an output row touches is found from three columns of the host's own axis
         // tables with the kernels' float32 arithmetic (+ 1 for the lower tap, + 1 row of margin).
-        // k_warp_stage stages a 32 x 8 output tile's source window (<= WS_NR rows of <= WS_NC pixels) through LDS; a tile whose window is larger
-        // gathers its taps like k_warp_lean.  Count, from the tile corners (and the frame's centre column / row where a tile straddles them: the
-        // map's extremes), how many tiles fit: below 80 % the gather build takes the whole launch.
-        c->warp_stage_ok = false;
-        if ((k.flags & CRTFX_F_WARP) && p->warp_xhat && p->warp_yhat && c->pix_fmt == CRTFX_PIX_U8) {
-            const float* xh = static_cast<const float*>(p->warp_xhat);
-            const float* yh = static_cast<const float*>(p->warp_yhat);
-            auto map = [&](int y, int x, int& ix, int& iy) {
-                const float xv = xh[x], yv = yh[y];
-                const float r2 = xv * xv + yv * yv;
-                const float factor = 1.0f + k.warp_k * r2;
-                const float mx = (xv * factor) * k.cx + k.cx, my = (yv * factor) * k.cy + k.cy;
-                ix = ((int)rintf(mx * 32.0f)) >> 5; iy = ((int)rintf(my * 32.0f)) >> 5;
-                ix = ix < -1 ? -1 : (ix > W ? W : ix); iy = iy < -2 ? -2 : (iy > H ? H : iy);
-            };
-            long fit = 0, tiles = 0;
-            for (int ty = 0; ty < H; ty += 8)
-                for (int tx = 0; tx < W; tx += 32) {
-                    const int x1 = tx + 31 < W ? tx + 31 : W - 1, y1 = ty + 7 < H ? ty + 7 : H - 1;
-                    int xs[3] = {tx, x1, (W / 2 >= tx && W / 2 <= x1) ? W / 2 : tx}, ys[3] = {ty, y1, (H / 2 >= ty && H / 2 <= y1) ? H / 2 : ty};
-                    int a0 = 1 << 30, a1 = -(1 << 30), b0 = 1 << 30, b1 = -(1 << 30);
-                    for (int yi = 0; yi < 3; ++yi) for (int xi = 0; xi < 3; ++xi) {
-                        int ix, iy; map(ys[yi], xs[xi], ix, iy);
-                        a0 = ix < a0 ? ix : a0; a1 = ix > a1 ? ix : a1; b0 = iy < b0 ? iy : b0; b1 = iy > b1 ? iy : b1;
-                    }
-                    ++tiles;
-                    if (b1 - b0 + 2 <= WS_NR && a1 - a0 + 2 <= WS_NC) ++fit;
-                }
-            c->warp_stage_ok = tiles > 0 && fit * 5 >= tiles * 4;
-            if (c->debug_plan) fprintf(stderr, "[crtfx] k_warp_stage: %ld of %ld 32 x 8 tiles fit their LDS window%s\n", fit, tiles, c->warp_stage_ok ? "" : " (gather build)");
-        }
         c->band_src.clear(); c->band_row.clear();
         const size_t frame_scratch = (size_t)H * W * 3 * sizeof(float);
         const size_t band_bytes = (size_t)(c->band_mb > 0 ? c->band_mb : 224) << 20;
@@ -1257,7 +1213,6 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
     case CRTFX_OPT_NO_CT: c->no_ct = value != 0; break;
     case CRTFX_OPT_NO_PLAIN_WARP: c->no_plain_warp = value != 0; break;
-    case CRTFX_OPT_NO_WARP_STAGE: c->no_warp_stage = value != 0; break;
     case CRTFX_OPT_BAND_MB: if (value < -1 || value > 4096) return fail(c, CRTFX_E_INVALID, "band_mb %d outside -1..4096", value); c->band_mb = value; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;
     case CRTFX_OPT_SPLIT_SRC_PLANE: c->split_src_plane = value != 0; break;

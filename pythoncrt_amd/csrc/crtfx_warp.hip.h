@@ -283,135 +283,6 @@ __global__ __launch_bounds__(256, (PLAIN ? WARP_PLAIN_WAVES : 1)) void k_warp_le
 #endif  // CRTFX_MAIN_TU
 
 #ifdef CRTFX_MAIN_TU
-// ---------------------------------------------------------------------------------------
-// k_warp_stage — k_warp_lean's branch-free build with the gather taken OFF the texture-address unit.
-// Round 4's counters put that kernel's TA busy 75 % of the time with its address / command FIFOs full 5 - 7 M times per launch: sixteen
-// 12-byte tap loads per thread, each costing the TA what a full-width load costs.  Here a WAVE owns a 32 x 8 output tile (lane = column,
-// the two half-waves rows 0-3 / 4-7), finds the source window its 256 pixels' taps span — rows [rmin, rmax], columns [cmin, cmax], a
-// packed-int16 min / max butterfly over the lanes: the barrel map is smooth, 8 output rows x 32 columns touch 8 x 1.3 + 2 + 32 x 0.084 < 16
-// rows of <= 41 pixels at warp 0.15 — and loads those rows WHOLE: one 16-byte load per lane = two 512-byte row segments per instruction,
-// at most 8 instructions per wave instead of 16, into a wave-private LDS tile (no barrier: LDS operations of one wave execute in order).
-// The taps then come out of LDS at (iy - rmin, ix - cmin); weights, masks, the float64 sums and the quantisation are k_warp_lean's, so are
-// the bits (a tap outside the image is a buffer offset outside the resource -> 0, or a neighbouring row's pixel under a zero weight, as
-// there).  A wave whose window does not fit (strong warps) gathers its taps the old way — a wave-uniform branch.
-// ---------------------------------------------------------------------------------------
-#ifndef WS_NR_
-#define WS_NR_ 16
-#endif
-#ifndef WS_WAVES
-#define WS_WAVES 1
-#endif
-constexpr int WS_NR = WS_NR_;             // staged rows per wave (two per load instruction)
-constexpr int WS_ROWB = 528;              // LDS bytes per staged row: 16 zero bytes (the tap of column -1) + 512 of data (one 16-byte load per lane of a half-wave)
-constexpr int WS_NC = 41;                 // pixels of a row the window may span whatever its alignment (41 * 12 + 12 of alignment slack <= 512): the host's estimate
-typedef __attribute__((address_space(3))) uint32_t ws_lds_u32;
-typedef uint32_t ws_u32x4 __attribute__((ext_vector_type(4)));
-typedef short ws_i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t ws_pk(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
-__device__ __forceinline__ uint32_t ws_min2(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ws_i16x2, a), __builtin_bit_cast(ws_i16x2, b))); }
-__device__ __forceinline__ uint32_t ws_max2(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ws_i16x2, a), __builtin_bit_cast(ws_i16x2, b))); }
-
-template <bool PROMOTE>
-__global__ __launch_bounds__(256, WS_WAVES) void k_warp_stage(KParams P, KWarpGroup G) {
-    using T = typename std::conditional<PROMOTE, double, float>::type;
-    __shared__ __attribute__((aligned(16))) uint32_t tile[4][WS_NR * WS_ROWB / 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int cxl = lane & 31, hf = lane >> 5;
-    const int x0 = ((int)blockIdx.x * 4 + wv) * 32;
-    const int yb = G.y0 + (int)blockIdx.y * 8 + 4 * hf;
-    if (x0 >= P.W) return;                                   // wave-uniform
-    const int x = min(x0 + cxl, P.W - 1);
-    float u00[4], u01[4], u10[4], u11[4];
-    int ixc[4], iyc[4];
-    int ixlo = 32767, ixhi = -32768, iylo = 32767, iyhi = -32768;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = min(yb + r, P.H - 1);                   // a row past the bottom redoes the last one; its stores fall outside the output buffer
-        int ix, iy, fx, fy;
-        warp_coords(P, y, x, ix, iy, fx, fy);
-        const float wx1 = (float)fx * 0.03125f, wx0 = 1.0f - wx1;
-        const float wy1 = (float)fy * 0.03125f, wy0 = 1.0f - wy1;
-        const float mx0 = (unsigned)ix < (unsigned)P.W ? wx0 : 0.0f, mx1 = (unsigned)(ix + 1) < (unsigned)P.W ? wx1 : 0.0f;
-        u00[r] = wy0 * mx0; u01[r] = wy0 * mx1; u10[r] = wy1 * mx0; u11[r] = wy1 * mx1;
-        ixc[r] = min(max(ix, -1), P.W); iyc[r] = min(max(iy, -2), P.H);      // k_warp_lean's clamps: same offsets, same zeros
-        ixlo = min(ixlo, ixc[r]); ixhi = max(ixhi, ixc[r]); iylo = min(iylo, iyc[r]); iyhi = max(iyhi, iyc[r]);
-    }
-    // the wave's source window: packed (row, column) int16 pairs through a butterfly — every lane ends with the wave's min and max
-    uint32_t lo2 = ws_pk(iylo, ixlo), hi2 = ws_pk(iyhi, ixhi);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        lo2 = ws_min2(lo2, (uint32_t)__shfl_xor((int)lo2, m));
-        hi2 = ws_max2(hi2, (uint32_t)__shfl_xor((int)hi2, m));
-    }
-    lo2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo2); hi2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi2);
-    const int rmin = (int)(short)(lo2 & 0xFFFFu), cmin = (int)(short)(lo2 >> 16);
-    const int rmax = (int)(short)(hi2 & 0xFFFFu) + 1, cmax = (int)(short)(hi2 >> 16) + 1;      // + 1: the lower / right-hand tap
-    const int nrows = rmax - rmin + 1;
-    // the staged columns start on a 16-byte boundary at or left of column max(cmin, 0): no load starts left of a row (a vector load whose
-    // first byte lies outside the resource returns zeros for ALL its dwords — measured: the first pixel of row 0 lost its red sample), and,
-    // rows being whole multiples of 16 bytes (W % 4 == 0), none straddles the image's last byte.  The tap of column -1 (weight 0) then reads
-    // the 16 zero bytes kept in front of every staged row.
-    const int cs = __mul24(max(cmin, 0), 12) & ~15;
-    const int span = (cmax + 1) * 12 - cs;                   // bytes of a row the taps can touch
-    const float* __restrict__ pre = G.pre[blockIdx.z];
-    const KOut O = G.o[blockIdx.z];
-    const __amdgpu_buffer_rsrc_t pre_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pre), 0, (int)((uint32_t)P.H * (uint32_t)P.W * 12u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(O.out_u8, 0, (int)((uint32_t)P.H * (uint32_t)P.W * 3u), 0x00020000);
-    WarpTaps taps[4];
-    if (nrows <= WS_NR && span <= WS_ROWB - 16) {             // wave-uniform
-        const uint32_t wbase = (uint32_t)(uintptr_t)(ws_lds_u32*)&tile[wv][0];
-        if (lane < WS_NR) *(__attribute__((address_space(3))) ws_u32x4*)(uintptr_t)(wbase + (uint32_t)(lane * WS_ROWB)) = ws_u32x4{0u, 0u, 0u, 0u};
-        // row s = 2 q + half of the window, 16 bytes per lane; rows past the window's end (and rows above / below the image) get an offset
-        // outside the resource: they read as zeros and touch no memory
-        const uint32_t col_b = (uint32_t)cs + (uint32_t)cxl * 16u;
-        ws_u32x4 st[WS_NR / 2];
-#pragma unroll
-        for (int q = 0; q < WS_NR / 2; ++q) {
-            const int srow = 2 * q + hf;
-            const uint32_t off = srow < nrows ? (uint32_t)__mul24(rmin + srow, P.W * 12) + col_b : 0xFFFFFFF0u;
-            st[q] = __builtin_amdgcn_raw_buffer_load_b128(pre_rs, off, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < WS_NR / 2; ++q)
-            *(__attribute__((address_space(3))) ws_u32x4*)(uintptr_t)(wbase + (uint32_t)((2 * q + hf) * WS_ROWB) + 16u + (uint32_t)cxl * 16u) = st[q];
-        __builtin_amdgcn_wave_barrier();                      // LDS operations of a wave execute in order; this only stops the compiler from moving the reads up
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t a = wbase + (uint32_t)((iyc[r] - rmin) * WS_ROWB + 16 + ixc[r] * 12 - cs);
-            const ws_lds_u32* p0 = (const ws_lds_u32*)(uintptr_t)a;
-            const ws_lds_u32* p1 = (const ws_lds_u32*)(uintptr_t)(a + WS_ROWB);
-            taps[r].A = F3{__uint_as_float(p0[0]), __uint_as_float(p0[1]), __uint_as_float(p0[2])};
-            taps[r].B = F3{__uint_as_float(p0[3]), __uint_as_float(p0[4]), __uint_as_float(p0[5])};
-            taps[r].C = F3{__uint_as_float(p1[0]), __uint_as_float(p1[1]), __uint_as_float(p1[2])};
-            taps[r].D = F3{__uint_as_float(p1[3]), __uint_as_float(p1[4]), __uint_as_float(p1[5])};
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t oa = (uint32_t)(__mul24(iyc[r], P.W * 12) + __mul24(ixc[r], 12)), ob = oa + (uint32_t)P.W * 12u;
-            taps[r].A = buf_load_px(pre_rs, oa); taps[r].B = buf_load_px(pre_rs, oa + 12u);
-            taps[r].C = buf_load_px(pre_rs, ob); taps[r].D = buf_load_px(pre_rs, ob + 12u);
-        }
-    }
-    // the uint8 rows: each half-wave packs its 32 pixels' 96 bytes into 24 dwords (lanes 0..23 of the half)
-    const int valid = min(32, P.W - x0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        taps[r].u00 = u00[r]; taps[r].u01 = u01[r]; taps[r].u10 = u10[r]; taps[r].u11 = u11[r];
-        T v0, v1, v2;
-        warp_combine<T>(taps[r], v0, v1, v2);
-        const uint32_t packed = quant_u8x3((float)v0, (float)v1, (float)v2);
-        const int a = (4 * cxl) / 3, o = 4 * cxl - 3 * a;
-        const uint32_t lo = __shfl(packed, hf * 32 + (a & 31)), hi = __shfl(packed, hf * 32 + ((a + 1) & 31));
-        const uint32_t dw = (uint32_t)(((uint64_t)lo | ((uint64_t)hi << 24)) >> (8 * o));
-        const int y = yb + r;                                  // y >= H: the offset is past the buffer's end, the store is dropped
-        const uint32_t off = (cxl < 24 && 4 * cxl + 4 <= valid * 3) ? __umul24((uint32_t)y, (uint32_t)P.W * 3u) + (uint32_t)x0 * 3u + 4u * (uint32_t)cxl : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_buffer_store_b32(dw, out_rs, off, 0, 2);
-    }
-}
-#endif  // CRTFX_MAIN_TU
-
-#ifdef CRTFX_MAIN_TU
 // crtfx_scanline_plane — make_scanline_mask_2d (ref:308-328) on the device: the slanted / thickness-shaped scanline
 // gain the reference rebuilds on the CPU for every frame (float64 sin and pow per pixel, then cast to float32).
 // Same expression tree in double; the device's sin/pow are not numpy's, so a value can come out one float32 ulp

@@ -469,7 +469,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
     for name, opts in (("folded", {}), ("cc", {"FORCE_CC": 1}), ("cc_no_ct", {"FORCE_CC": 1, "NO_CT": 1}), ("no_cc", {"NO_CC": 1}), ("runtime_flags", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}),
                        ("split", {"SPLIT_FROM": 0}), ("split_plane", {"SPLIT_FROM": 0, "SPLIT_SRC_PLANE": 1}),
                        ("warp_rows_1", {"WARP_ROWS": 1}), ("warp_rows_2", {"WARP_ROWS": 2}), ("warp_rows_4", {"WARP_ROWS": 4}),      # k_warp_lean's tile shapes (0 = the launcher's choice)
-                       ("no_plain_warp", {"NO_PLAIN_WARP": 1}), ("no_warp_stage", {"NO_WARP_STAGE": 1})):      # ... its general build where the branch-free one is the default; its gather where the LDS-staged kernel is
+                       ("no_plain_warp", {"NO_PLAIN_WARP": 1})):      # ... and its general build where the branch-free one is the default
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}          # the switches are applied when a ctx is created
         res = []
@@ -496,7 +496,7 @@ def test_kernel_variants_agree(pc, monkeypatch):
                 res.append(keep.cpu().numpy())      # the per-frame states the sharded render's fix-up reads (written even when a run keeps its state in registers)
         outs[name] = res
     effects._tls.engines = {}
-    for name in ("cc", "cc_no_ct", "no_cc", "runtime_flags", "generic", "split", "split_plane", "warp_rows_1", "warp_rows_2", "warp_rows_4", "no_plain_warp", "no_warp_stage"):
+    for name in ("cc", "cc_no_ct", "no_cc", "runtime_flags", "generic", "split", "split_plane", "warp_rows_1", "warp_rows_2", "warp_rows_4", "no_plain_warp"):
         for x, y in zip(outs["folded"], outs[name]):
             assert np.array_equal(x, y), name
 
@@ -798,31 +798,6 @@ def test_fp16_frames(pc, cfg):
     exp16 = np.abs(so.astype(np.float32) * np.float32(255.0)).astype(np.float16)
     assert np.abs(ug.astype(np.float32) - exp16.astype(np.float32)).max() <= 0.125      # one half ulp at 128..255
     assert (ug != exp16).mean() < 5e-3          # half is 32x finer than uint8 around 200: more last-bit flips per float ulp
-
-
-def test_warp_stage_equals_gather(pc, monkeypatch):
-    """k_warp_stage — a wave loads the source rows its 32 x 8 output tile touches whole into LDS and takes the bilinear taps from there —
-    against k_warp_lean's gather (NO_WARP_STAGE) and the general k_warp (FORCE_GENERIC): identical frames for gentle maps (every wave
-    staged), strong and pincushion maps (waves whose window does not fit gather; below 80 % fitting tiles the launcher does not take the
-    kernel at all), frames narrower than a tile, widths that are not a multiple of the tile, rows past the bottom, and several radii."""
-    from pythoncrt_amd import effects
-    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
-    dev = torch.device("cuda", torch.cuda.current_device())
-    n = 2
-    for (h, w, warp, sigma) in [(270, 480, 0.15, 3.0), (203, 264, 0.15, 1.2), (64, 36, 0.15, 2.0), (130, 700, 0.05, 3.0), (300, 512, -0.15, 3.0),
-                                (257, 384, 0.5, 3.0), (180, 320, 1.0, 1.2), (180, 320, -1.0, 1.2), (9, 128, 0.15, 1.2), (540, 960, 0.3, 3.0)]:
-        frames = torch.from_numpy(np.stack([make_frame(h, w, seed=90 + i, kind="grad") for i in range(n)])).to(dev)
-        rs = RenderSettings(fast_bloom=False, bloom_sigma=sigma, pixel_size=1, persistence=0.0, warp_strength=warp)
-        outs = {}
-        for name, opts in (("stage", {}), ("gather", {"NO_WARP_STAGE": 1}), ("general", {"FORCE_GENERIC": 1})):
-            monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
-            effects._tls.engines = {}
-            pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=21)
-            out, _ = pipe.run(frames, first_index=1)
-            outs[name] = out.cpu().numpy()
-        assert np.array_equal(outs["stage"], outs["gather"]), (h, w, warp)
-        assert np.array_equal(outs["stage"], outs["general"]), (h, w, warp)
-    effects._tls.engines = {}
 
 
 @pytest.mark.parametrize("half", [False, True])
