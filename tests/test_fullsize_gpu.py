@@ -79,6 +79,40 @@ def test_8k_fp16_frame_against_oracle(dev):
     assert (got != exp16).mean() < 5e-3, float((got != exp16).mean())     # half is 32x finer than uint8 around 200
 
 
+@pytest.mark.parametrize("ab,hw,sigma", [(1, (40, 448), 3.0), (0, (33, 702), 1.2), (-3, (40, 448), 3.0), (8, (24, 640), 4.4), (1, (30, 449), 3.0), (-8, (40, 320), 3.0)])
+def test_fp16_wide_frames_against_oracle(dev, ab, hw, sigma):
+    """Half frames wide enough to have interior strips (the small fp16 cases of test_parity_gpu.py are all edge strips), every aberration
+    sign and size, three radii, an odd width: the half output frame of the gate-folded k_phosphor_rr<half> against the oracle's float image
+    narrowed the same way, and the same frames on an allocation that does not start on a dword.  (A pixel-pair A phase for this build —
+    one 12-byte load per two pixels instead of six 2-byte loads — was measured 17 % SLOWER in round 4, profiles/r04_8k_bands.txt, and is
+    not in the tree; this test is what held it to the oracle.)"""
+    import dataclasses
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    h, w = hw
+    rs = dataclasses.replace(baseline_config(5)[0], aberration_px=ab, bloom_sigma=sigma, warp_strength=0.0)
+    first, seed, n = 4, 99, 2
+    rng = np.random.default_rng(500 + ab)
+    frames = (rng.random((n, h, w, 3), dtype=np.float32) * 255.0).astype(np.float16)
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed, dtype=torch.float16)
+    out, _ = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    got = out.cpu().numpy()
+    planes = _export_planes(pipe, seed, first, n, h, w)
+    params = {k: getattr(rs, k) for k in PARAM_KEYS}
+    for i in range(n):
+        _, st = orc.process_frames([frames[i]], params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                   rs.vignette_strength, noise_planes=[planes[i]], first_index=first + i)
+        exp16 = np.abs(st.astype(np.float32) * np.float32(255.0)).astype(np.float16)
+        diff = np.abs(got[i].astype(np.float32) - exp16.astype(np.float32))
+        assert diff.max() <= 0.125 and (got[i] != exp16).mean() < 5e-3, (ab, hw, i, float(diff.max()), float((got[i] != exp16).mean()))      # the bar of the 8K test
+    # the same frames two bytes into an allocation (not on a dword): the per-sample path, the same bits
+    raw = torch.zeros(frames.size * 2 + 8, dtype=torch.uint8, device=dev)
+    shifted = raw[2:2 + frames.size * 2].view(torch.float16).view(n, h, w, 3)
+    shifted.copy_(torch.from_numpy(frames).to(dev))
+    assert shifted.data_ptr() % 4 == 2
+    out2, _ = pipe.run(shifted, first_index=first)
+    assert torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("speed", [30.0, 31.7])       # integer phases (one shared table, regenerated far ahead) / fractional phases (one table per batch)
 def test_records_built_ahead_of_their_launches(dev, speed):
     """frame_records() for several batches BEFORE the first of them runs (bench.py --tables-outside, GpuShardEngine.records):
