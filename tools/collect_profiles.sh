@@ -24,6 +24,19 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -- python3 $R/bench.py $X $PB > $OUT/${TAG}_write.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/${TAG}_sq -- python3 $R/bench.py $X $PB > $OUT/${TAG}_sq.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_sq2 -- python3 $R/bench.py $X $PB > $OUT/${TAG}_sq2.log 2>&1
+# the raw counter CSVs of a 256-frame batch are tens of MB (gpurun brings back at most 64 MiB): keep the per-kernel means, drop the rows
+for part in fetch write sq sq2; do
+python3 - "$OUT/${TAG}_$part" <<'PY'
+import collections, csv, glob, json, os, sys
+d = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    os.remove(f)
+json.dump({k: {c: sum(v) / len(v) for c, v in dd.items()} for k, dd in agg.items()}, open(d + "_agg.json", "w"))
+PY
+done
 # FETCH_SIZE on a known, cold byte count in this code's own load shapes (tools/ubench/fetch_calib.hip)
 if [ -x $R/build/ubench/fetch_calib ]; then
   timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_calib -- $R/build/ubench/fetch_calib > $OUT/${TAG}_calib.log 2>&1

@@ -18,6 +18,9 @@ newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]      # gpurun_out/ acc
 
 
 def counters(part):
+    agg_file = f"gpurun_out/{tag}_{part}_agg.json"          # per-kernel means made on the GPU box (tools/collect_profiles.sh); else the raw rows
+    if os.path.exists(agg_file):
+        return json.load(open(agg_file))
     fs = newest(glob.glob(f"gpurun_out/{tag}_{part}/**/*counter_collection.csv", recursive=True))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in (csv.DictReader(open(fs[0])) if fs else []):
