@@ -67,6 +67,28 @@ def test_cli_matches_pipeline_and_oracle(pc, tmp_path):
     assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
 
 
+def test_cli_pipes_equal_files(pc, tmp_path):
+    """`--input - --output -` (the drop-in between two ffmpeg processes): the reader thread takes the frames from stdin
+    sequentially, the writer thread puts them on stdout in order — the same bytes as the file-to-file run (memory-mapped input, positional
+    writes), over more batches than there are staging slots, a short last batch, a trailing partial frame, persistence carried across
+    batches; `--staging-report` goes to stderr only."""
+    import subprocess
+    import sys
+    n, h, w = 11, 48, 96
+    frames = clip(n, h, w, 8)
+    extra = ["--noise-strength", "0.8", "--warp-strength", "0.1", "--persistence", "0.3"]
+    ref = run_cli(pc, tmp_path, frames, extra, batch=2)
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "pythoncrt_amd.cli", "--input", "-", "--output", "-", "--width", str(w), "--height", str(h), "--fps", "30",
+           "--batch", "2", "--noise-seed", "99", "--staging-report"] + extra
+    r = subprocess.run(cmd, input=frames.tobytes() + b"\x07\x08", capture_output=True, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:].decode(errors="replace")
+    out = np.frombuffer(r.stdout, dtype=np.uint8)
+    assert out.size == n * h * w * 3, (out.size, r.stderr[-500:])
+    assert np.array_equal(out.reshape(n, h, w, 3), ref)
+    assert b"staging" in r.stderr and f"{n} frames".encode() in r.stderr
+
+
 def test_cli_text_overlay_and_grain(pc, tmp_path):
     """--text draws through Pillow and blends on the GPU; the grain is reproducible from --noise-seed."""
     from pythoncrt_amd import cli, text
