@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box: the committed bench line of a round and the N > 1 rehearsal (several gloo ranks on the box's ONE GPU: the line end to end, not a scaling result;
+# the box admits six GPU processes and the launcher is one of them, hence five ranks).   bash tools/final_lines.sh   -> gpurun_out/r04_z_bench.json, r04_five_rank_rehearsal.txt
 set -o pipefail
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out
 python3 $R/bench.py > $OUT/r04_z_bench.json 2> $OUT/r04_z_bench.err
