@@ -116,6 +116,7 @@ class FramePipeline:
         self.overlay_after = bool(text_overlay_after)
         self.noise_seed = int(noise_seed)
         self.dtype = dtype                  # torch.uint8, or torch.float16 (half frames on the 0..255 scale)
+        self._glitch_stage = {}             # (frames, rows, segments) -> two [pinned int32 block, upload event] pairs (frame_records)
         self.engine = Engine(device, h, w, _lib.PIX_F16 if dtype == torch.float16 else _lib.PIX_U8)
         self.static = settings.static_settings(self.h, self.w)
         self.engine.set_params(self.static)
@@ -159,12 +160,26 @@ class FramePipeline:
             drawn = list(_glitch_pool().map(draw, idx)) if n > 1 else [draw(idx[0])]
             if drawn and drawn[0][1] is not None:
                 rows, cols = drawn[0][1].shape
-                host = torch.empty((n, rows, cols), dtype=torch.int32).pin_memory()
+                # two pinned staging blocks per shape, reused in turn (a fresh hipHostMalloc per batch made one step in three take 15-80 ms
+                # instead of 6: profiles/r04_cli_scan.txt); a block is rewritten only once the upload that last read it has completed
+                slots = self._glitch_stage.setdefault((n, rows, cols), [])
+                if len(slots) < 2:
+                    slots.append([torch.empty((n, rows, cols), dtype=torch.int32).pin_memory(), None])
+                    host, ev = slots[-1][0], None
+                    k = len(slots) - 1
+                else:
+                    k = self._glitch_turn = (getattr(self, "_glitch_turn", 0) + 1) & 1
+                    host, ev = slots[k]
+                if ev is not None:
+                    ev.synchronize()
                 hv = host.numpy()
                 for j, (_, offs, _) in enumerate(drawn):
                     hv[j] = offs
                 dev = host.to(self.device, non_blocking=True)
-                hold += [host, dev]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                slots[k][1] = ev
+                hold += [dev]
                 recs["glitch_offs_dev"] = dev.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(rows * cols * 4)
                 recs["glitch_y0"], recs["glitch_cols"], recs["glitch_seg_len"] = int(drawn[0][0]), int(cols), int(drawn[0][2])
         if flick:
