@@ -99,19 +99,22 @@ def copy_ceiling(device):
     return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def mall_ceiling(frames_per_launch):
+def mall_ceiling(frames_per_launch, h=2160):
     """GB/s (float32 source + uint8 output bytes) at which a hand-written stream reads a launch group's pre-warp images back RIGHT AFTER they
     were written, from the committed run of tools/ubench/mall_copy.hip (profiles/r04_mall_copy.txt; 'x3' = one 12-byte pixel per lane):
     k_warp's yardstick — its source is kept under the 256 MB Infinity Cache on purpose, so the HBM-sized copy of `copy_ceiling` is the
     wrong one for it.  A committed measurement of the same chip model, not of this box: labelled as such."""
     import re
-    path = os.path.join(ROOT, "profiles", "r04_mall_copy.txt")
-    want = max(1, min(4, int(round(frames_per_launch))))
+    name = {2160: "r04_mall_copy.txt", 1080: "r04_mall_copy_1080p.txt"}.get(int(h))
+    if name is None:
+        return None
+    path = os.path.join(ROOT, "profiles", name)
+    want = max(1, int(round(frames_per_launch)))
     try:
         for line in open(path):
             m = re.match(r"(\d+) frame\(s\).*\bx3\s+([\d.]+) us\s+(\d+) GB/s", line)
             if m and int(m.group(1)) == want:
-                return {"gbs": float(m.group(3)), "us_per_group": float(m.group(2)), "frames": want, "source": "profiles/r04_mall_copy.txt (tools/ubench/mall_copy.hip, committed run)"}
+                return {"gbs": float(m.group(3)), "us_per_group": float(m.group(2)), "frames": want, "source": f"profiles/{name} (tools/ubench/mall_copy.hip, committed run)"}
     except OSError:
         pass
     return None
@@ -522,7 +525,7 @@ def main():
                 "valu": valu, "lds": lds,
                 "copy_ceiling": copy_ceiling(device),
                 # ... and what reading one launch group's float32 pre-warp images back out of the Infinity Cache reaches (k_warp's yardstick)
-                "mall_ceiling": mall_ceiling(fpl) if (rs.warp_strength != 0.0 and h == 2160) else None,
+                "mall_ceiling": mall_ceiling(fpl, h) if rs.warp_strength != 0.0 else None,
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
             }

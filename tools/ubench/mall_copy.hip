@@ -14,7 +14,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-constexpr int W = 3840, H = 2160;
+static int W = 3840, H = 2160;      // argv: W H frames...   (default: 4K, 1 - 4 frames)
 
 __global__ __launch_bounds__(256) void k_fill(f32x4* __restrict__ out, size_t n4) {
     size_t i = (size_t)blockIdx.x * 256 * 8 + threadIdx.x;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_read_x4(const f32x4* __restrict__ in, s
 __device__ __forceinline__ u32x3 ld3(__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0); }
 // one pixel per lane and row, 4 rows per thread (128 x 8 tiles as k_warp_lean)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_read_px(const float* __restrict__ in, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_read_px(const float* __restrict__ in, uint8_t* __restrict__ out, int W, int H) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = (blockIdx.x * 2 + (wv & 1)) * 64 + lane;
     const int yb = blockIdx.y * 8 + (wv >> 1);
@@ -87,9 +87,15 @@ __global__ __launch_bounds__(256) void k_read_px(const float* __restrict__ in, u
     }
 }
 
-int main() {
+#include <vector>
+#include <cstdlib>
+int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int frames : {1, 2, 3, 4}) {
+    std::vector<int> counts = {1, 2, 3, 4};
+    if (argc >= 3) { W = atoi(argv[1]); H = atoi(argv[2]); }
+    if (argc >= 4) { counts.clear(); for (int i = 3; i < argc; ++i) counts.push_back(atoi(argv[i])); }
+    printf("%d x %d float32 frames\n", W, H);
+    for (int frames : counts) {
         const size_t nfl = (size_t)W * H * 3 * frames, n4 = nfl / 4;
         float* buf; uint8_t* out;
         CK(hipMalloc(&buf, nfl * 4 + 65536)); CK(hipMalloc(&out, nfl + 65536));
@@ -109,9 +115,9 @@ int main() {
             return 0;
         };
         timed([&] { hipLaunchKernelGGL(k_read_x4, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, 0, (const f32x4*)buf, n4, (uint32_t*)out); }, "x4");
-        timed([&] { hipLaunchKernelGGL(k_read_px<0>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out); }, "x3");
-        timed([&] { hipLaunchKernelGGL(k_read_px<1>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out); }, "tap4");
-        timed([&] { hipLaunchKernelGGL(k_read_px<2>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out); }, "row2");
+        timed([&] { hipLaunchKernelGGL(k_read_px<0>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out, W, H); }, "x3");
+        timed([&] { hipLaunchKernelGGL(k_read_px<1>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out, W, H); }, "tap4");
+        timed([&] { hipLaunchKernelGGL(k_read_px<2>, dim3(W / 128, H / 8, frames), dim3(256), 0, 0, buf, out, W, H); }, "row2");
         CK(hipFree(buf)); CK(hipFree(out));
     }
     return 0;
