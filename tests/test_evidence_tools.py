@@ -60,3 +60,22 @@ def test_source_hash_covers_every_kernel_source():
     assert "crtfx.h" in names
     h = bench.source_hash()
     assert len(h) == 16 and int(h, 16) >= 0
+
+
+def test_bench_ceiling_and_telemetry_degrade_gracefully():
+    """bench.py's round-4 additions on a box without a GPU: the Infinity-Cache-resident ceiling comes from the committed microbenchmark
+    runs (4K groups, 1080p groups; nothing for other sizes), and the per-rank GPU telemetry turns into nulls with a note instead of raising
+    when rocm_smi / the device is unavailable."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.mall_ceiling(2.0)
+    assert a and a["frames"] == 2 and 6000 < a["gbs"] < 8000 and a["source"].startswith("profiles/r04_mall_copy.txt")
+    b = bench.mall_ceiling(5.0, 1080)
+    assert b and b["frames"] == 5 and b["us_per_group"] > 0 and "1080p" in b["source"]
+    assert bench.mall_ceiling(1.0, 4320) is None and bench.mall_ceiling(7.0, 2160) is None
+    import torch
+    t = bench.GpuTelemetry(torch.device("cpu"))
+    t.start()
+    out = t.stop()
+    assert out["sclk_mhz_mean"] is None and out["power_w_mean"] is None and out["samples"] == 0
