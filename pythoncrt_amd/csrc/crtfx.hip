@@ -389,6 +389,13 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
             plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr && (PIX != CRTFX_PIX_F16 || ((uintptr_t)wg.o[j].out_u8 & 3u) == 0);
         if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
     }
+    // a persistence chain of uint8 frames that all blend into ONE state buffer (the render loop's runs; not the sharded render's per-frame
+    // local states), rows of whole dwords: the branch-free build too
+    if constexpr (BLEND == CRTFX_BLEND_RENDER && PIX == CRTFX_PIX_U8 && SEQ) {
+        bool plain = rows == 2 && (c->W & 3) == 0 && !c->no_plain_warp && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);
+        for (int j = 0; j < ntot && plain; ++j) plain = wg.o[j].out_u8 != nullptr && wg.o[j].state != nullptr && wg.o[j].state == wg.o[0].state;
+        if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
+    }
     if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
     else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
     else { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 1, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
