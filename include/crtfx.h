@@ -244,6 +244,17 @@ typedef enum crtfx_option {
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 
+/* Which build of each kernel class the most recent crtfx_apply_static / crtfx_apply / crtfx_process_batch call of this ctx launched LAST, as a
+ * NUL-terminated `key=value;...` string (truncated to n - 1 characters), e.g.
+ *   phosphor=k_phosphor_ct<9,u8>;group=2;seg_rows=256;warp=k_warp_lean<f64,none,u8,rows=4,tile=128x16,plain>;warp_frames=2
+ * keys: phosphor (the fused Gaussian-bloom chain), blur (split bloom passes), half (fast-bloom source), point (pointwise chain), group (frames
+ * per grid of the phosphor / pointwise launch), seg_rows (rows per phosphor block), group_max (the planner's frames per grid: the last group of a
+ * batch may be shorter), warp, warp_frames.  Every variant of a kernel produces the
+ * same bits (tests/test_parity_gpu.py::test_kernel_variants_agree), so a planner regression is invisible to parity tests: this record is what
+ * tests/test_plan_gpu.py pins for the BASELINE configs.  (The reference has no counterpart: its "plan" is the fixed numpy / cv2 call sequence
+ * of ref:566-698.) */
+int crtfx_last_plan(crtfx_ctx* ctx, char* buf, size_t n);
+
 /* -DCRTFX_STAMP diagnostic builds only (tools/phase_profile.py): device buffer the per-wave phase cycle sums are
  * written to.  CRTFX_E_UNSUPPORTED in the product build. */
 int crtfx_debug_buffer(crtfx_ctx* ctx, void* dev_ptr);

@@ -420,7 +420,11 @@ def main_sharded(a, rank: int, world: int) -> int:
     # r+1 is scanned, results come back one call late; any other case runs the synchronous protocol behind the same calls
     # — over gloo (rehearsals).  Over RCCL the synchronous hop stays the default until the overlapped one has run on a multi-GPU
     # box (it costs ~0.3 ms per round: one state frame over one xGMI link + the fix-up); CRTFX_SHARD_OVERLAP=1 opts in.
-    overlap = backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1"
+    ov = os.environ.get("CRTFX_SHARD_OVERLAP")            # "1" / "0": force the overlapped / the synchronous schedule (tests run both over gloo)
+    overlap = (ov == "1") if ov in ("0", "1") else backend == "gloo"
+    # test hook: hold every download back by this many milliseconds of GPU time, so that a missing ordering between a round's download and the
+    # next round's kernels shows as wrong bytes instead of passing by timing (tests/test_cli_gpu.py::test_sharded_cli_synchronous_schedule)
+    down_delay_ms = float(os.environ.get("CRTFX_TEST_DOWNLOAD_DELAY_MS", "0") or 0)
     # three output slots: round r's frames may still be on their way to the host (download stream) while round r + 1 is scanned and —
     # overlapped schedule, results one call late — round r + 2 is enqueued
     render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=3), dist=dist, overlap=overlap)
@@ -449,6 +453,8 @@ def main_sharded(a, rank: int, world: int) -> int:
             ready.record(compute)                         # the round's kernels (and fix-up) are enqueued behind this point at the latest
             s_down.wait_event(ready)
             with torch.cuda.stream(s_down):
+                if down_delay_ms > 0:
+                    torch.cuda._sleep(int(down_delay_ms * 2.0e6))      # ~2 GHz shader clock; the exact length does not matter
                 writer.bufs[i][:n].copy_(out[:n], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(s_down)

@@ -71,6 +71,9 @@ struct crtfx_ctx {
     bool no_plain_warp = false;      // CRTFX_OPT_NO_PLAIN_WARP: k_warp_lean's branch-free build off (tests, A/B)
     bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
+    // crtfx_last_plan: which build each kernel class of the most recent apply / process_batch call landed on (every variant of a kernel is
+    // bit-identical by test, so only this record shows a planner regression)
+    struct Plan { char phosphor[80], warp[96], point[80], half[64], blur[64]; int group, seg_rows, warp_frames; } plan = {};
     bool debug_plan = false;
     std::string err;
     // profiling
@@ -191,6 +194,19 @@ struct ProfEv {
 
 size_t phosphor_rr_lds_bytes(int R, int seg_rows, bool pixelate, int pix = 0, bool runtime = false, bool glut = false);
 
+template <size_t N>
+void plan_note(char (&dst)[N], const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+template <size_t N>
+void plan_note(char (&dst)[N], const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, N, fmt, ap);
+    va_end(ap);
+}
+const char* sf_name(uint32_t sf) { return sf == SF_FAST ? "fast" : sf == SF_FAST_PIX ? "fast+pixelate" : sf == SF_RUNTIME ? "runtime" : "full"; }
+const char* pix_name(int pix) { return pix == CRTFX_PIX_F16 ? "half" : "u8"; }
+const char* blend_name(int b) { return b == CRTFX_BLEND_RENDER ? "render" : b == CRTFX_BLEND_PREVIEW ? "preview" : "none"; }
+
 // Rows per k_phosphor block.  Every block of the grid should be resident at once (a second,
 // partial round of blocks costs a whole extra block lifetime), so the grid is sized to the
 // number of block slots: blocks-per-CU (LDS-limited) x 256 CUs.  Measured (4K, R=9): 128 rows x 1020
@@ -222,7 +238,7 @@ struct GridPlan { int g, seg; };
 GridPlan plan_grid(int H, int W, int R, int pix, bool folded, bool glut, int gmin, int gmax_allowed, int cc = 0) {      // cc: 0 = k_phosphor_rr, 1 = k_phosphor_cc, 2 = k_phosphor_ct
     const int strips = (W + TW - 1) / TW;
     const int Rk = rr_build_radius(R) ? R : 9;
-    const size_t lds = cc == 2 ? (size_t)ct_lds_words(Rk) * 4 : cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
+    const size_t lds = cc == 2 ? (size_t)ct_lds_words(Rk, pix) * 4 : cc ? (size_t)cc_lds_words(Rk, pix) * 4 : phosphor_rr_lds_bytes(Rk, 128, false, pix, !folded, glut);
     int bpc = (int)(163840 / lds);
     const int by_regs = cc == 2 ? ct_min_waves(Rk) : cc ? cc_min_waves(Rk) : rr_min_waves(Rk, folded);      // a block = one wave per SIMD
     bpc = bpc > by_regs ? by_regs : (bpc < 1 ? 1 : bpc);
@@ -268,6 +284,8 @@ void launch_generic(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t 
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (c->H + seg - 1) / seg;
     ProfEv pe(c, 0);
+    plan_note(c->plan.phosphor, "k_phosphor<-1>");
+    c->plan.group = 1; c->plan.seg_rows = seg;
     CRTFX_LAUNCH((k_phosphor<-1>), dim3(strips, segs), dim3(K1_THREADS), phosphor_lds_bytes(c->kp.R), s, pe.e0, pe.e1, c->kp, kf, ko, seg);
 }
 
@@ -291,6 +309,13 @@ constexpr int CT_MAX_RADIUS = 15;      // k_phosphor_ct keeps four blocks per CU
 bool use_cc(const crtfx_ctx* c, int R) {
     const bool by_radius = c->force_cc || R >= CC_MIN_RADIUS || (!c->no_ct && R >= 1 && R <= CT_MAX_RADIUS);
     return c->pix_fmt == CRTFX_PIX_U8 && by_radius && (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31);
+}
+// Half frames: k_phosphor_ct<R, 1> for radii 1 .. CT_HALF_MAX_RADIUS (round 5: qword loads of the frame-row window, the centre samples in a register
+// window instead of an LDS ring — 34.8 KB of LDS, four blocks per CU); there is no half build of k_phosphor_cc.  Its loads address the frame
+// with 32-bit byte offsets.
+bool use_ct_half(const crtfx_ctx* c, int R) {
+    return c->pix_fmt == CRTFX_PIX_F16 && !c->no_ct && !c->no_cc && R >= 1 && R <= CT_HALF_MAX_RADIUS &&
+           (size_t)c->H * c->W * 3 * sizeof(float) < ((size_t)1 << 31) && (size_t)c->H * c->W * 6 < ((size_t)1 << 32);
 }
 
 // g frames (1..MAX_GROUP) through the register-window kernel in one launch.
@@ -325,16 +350,25 @@ void launch_rr_group(crtfx_ctx* c, const KGroup& kg_in, int g, hipStream_t s, in
     // ... whose A phase reads a frame row as aligned dwords: a caller's frame that does not start on a 4-byte boundary (an odd base pointer
     // or frame stride through the C-ABI; torch allocations never are) takes the byte-wise k_phosphor_cc — same bits
     for (int j = 0; j < g && ct; ++j) ct = ((uintptr_t)kg.f[j].in & 3u) == 0;
+    // half frames: the qword-load build of k_phosphor_ct (frames on an 8-byte boundary; else the register-window kernel — same bits)
+    bool cth = folded && !pix_fold && use_ct_half(c, R);
+    for (int j = 0; j < g && cth; ++j) cth = kg.o[j].pre != nullptr && ((uintptr_t)kg.f[j].in & 7u) == 0;
+    if (cth) ct = true;
     int& seg_slot = c->seg_for[ct ? 3 : cc ? 2 : (folded ? 1 : 0)][g];
     if (!seg_slot) seg_slot = c->opt_seg_rows ? c->opt_seg_rows : plan_grid(c->H, c->W, R, c->pix_fmt, folded, c->kp.grade_lut != nullptr, g, g, ct ? 2 : cc ? 1 : 0).seg;   // planned once per (kernel build, group size)
     const int seg = seg_rows > 0 ? seg_rows : seg_slot;
     const int strips = (c->W + TW - 1) / TW;
     const int segs = (kg.y1 - kg.y0 + seg - 1) / seg;
-    const int variant = ct ? 6 : cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
+    const int variant = cth ? 7 : ct ? 6 : cc ? 4 : (c->pix_fmt == CRTFX_PIX_F16 ? (folded ? 2 : 3) : (folded ? (pix_fold ? 5 : 1) : 0));
     const bool runtime = !folded;
-    const size_t lds = ct ? (size_t)ct_lds_words(R) * 4 : cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
+    const size_t lds = ct ? (size_t)ct_lds_words(R, c->pix_fmt) * 4 : cc ? (size_t)cc_lds_words(R, c->pix_fmt) * 4
                           : phosphor_rr_lds_bytes(R, seg, (c->kp.flags & CRTFX_F_PIXELATE) != 0, c->pix_fmt, runtime, c->kp.grade_lut != nullptr);
     ProfEv pe(c, 0, prof_frames >= 0 ? prof_frames : g);
+    if (cth) plan_note(c->plan.phosphor, "k_phosphor_ct<%d,half>", R);
+    else if (ct) plan_note(c->plan.phosphor, "k_phosphor_ct<%d,u8>", R);
+    else if (cc) plan_note(c->plan.phosphor, "k_phosphor_cc<%d,u8>", R);
+    else plan_note(c->plan.phosphor, "k_phosphor_rr<%d,%s,%s>", R, folded ? (pix_fold ? "full+pixelate" : "full") : "runtime", pix_name(c->pix_fmt));
+    c->plan.group = g; c->plan.seg_rows = seg;
     table[R](c->kp, kg, seg, dim3(strips, segs, g), lds, s, variant, pe.e0, pe.e1);
 }
 
@@ -353,6 +387,7 @@ void launch_phosphor(crtfx_ctx* c, const KFrame& kf, const KOut& ko, hipStream_t
 
 template <uint32_t SF, int BLEND>
 void launch_point_lean2(crtfx_ctx* c, dim3 grid, dim3 block, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const KFrame& kf, const KOut& ko) {
+    plan_note(c->plan.point, "k_point_lean<%s,%s,%s>", sf_name(SF), pix_name(c->pix_fmt), blend_name(BLEND));
     if (c->pix_fmt == CRTFX_PIX_F16) { CRTFX_LAUNCH((k_point_lean<SF, CRTFX_PIX_F16, BLEND>), grid, block, 0, s, e0, e1, c->kp, kf, ko); }
     else { CRTFX_LAUNCH((k_point_lean<SF, CRTFX_PIX_U8, BLEND>), grid, block, 0, s, e0, e1, c->kp, kf, ko); }
 }
@@ -379,6 +414,8 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
     grid.x = (grid.x + WX - 1) / WX;
     grid.y = ((int)grid.y + (4 / WX) * rows - 1) / ((4 / WX) * rows);      // the caller's grid.y = the ROWS to cover (a band, or the frame)
     grid.z = (ntot + nseq - 1) / nseq;
+    c->plan.warp_frames = ntot;
+    plan_note(c->plan.warp, "k_warp_lean<%s,%s,%s,rows=%d,tile=%dx%d,general>", PROMOTE ? "f64" : "f32", blend_name(BLEND), pix_name(PIX), rows, 64 * WX, (4 / WX) * rows);
     // (Padding the 60 tile columns of a 4K frame to 64 — a tile and the tile below it then land on the same XCD, eight
     // dispatches apart, to share their source rows in its L2 — measured SLOWER: 60.0 vs 57.4 us per 2-frame launch.)
     // the headline shape — unblended uint8 frames, none of which keeps a float state, rows of whole dwords — on the branch-free build
@@ -387,14 +424,20 @@ void launch_warp_lean2(crtfx_ctx* c, const KWarpGroup& wg, dim3 grid, int ntot, 
         bool plain = rows == 4 && !c->no_plain_warp && (PIX == CRTFX_PIX_F16 ? (c->W & 1) == 0 && (size_t)c->H * c->W * 6 < ((size_t)1 << 31) : (c->W & 3) == 0);
         for (int j = 0; j < ntot && plain; ++j)
             plain = wg.o[j].out_u8 != nullptr && wg.o[j].state == nullptr && (PIX != CRTFX_PIX_F16 || ((uintptr_t)wg.o[j].out_u8 & 3u) == 0);
-        if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
+        if (plain) {
+            plan_note(c->plan.warp, "k_warp_lean<%s,%s,%s,rows=4,tile=%dx%d,plain>", PROMOTE ? "f64" : "f32", blend_name(BLEND), pix_name(PIX), 64 * WX, (4 / WX) * 4);
+            CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return;
+        }
     }
     // a persistence chain of uint8 frames that all blend into ONE state buffer (the render loop's runs; not the sharded render's per-frame
     // local states), rows of whole dwords: the branch-free build too
     if constexpr (BLEND == CRTFX_BLEND_RENDER && PIX == CRTFX_PIX_U8 && SEQ) {
         bool plain = rows == 2 && (c->W & 3) == 0 && !c->no_plain_warp && (size_t)c->H * c->W * 12 < ((size_t)1 << 31);
         for (int j = 0; j < ntot && plain; ++j) plain = wg.o[j].out_u8 != nullptr && wg.o[j].state != nullptr && wg.o[j].state == wg.o[0].state;
-        if (plain) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return; }
+        if (plain) {
+            plan_note(c->plan.warp, "k_warp_lean<%s,%s,%s,rows=2,tile=%dx%d,plain>", PROMOTE ? "f64" : "f32", blend_name(BLEND), pix_name(PIX), 64 * WX, (4 / WX) * 2);
+            CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ, true>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); return;
+        }
     }
     if (rows == 4) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 4, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
     else if (rows == 2) { CRTFX_LAUNCH((k_warp_lean<PROMOTE, BLEND, PIX, 2, false, WX, SEQ>), grid, dim3(256), 0, s, e0, e1, c->kp, wg, nseq, ntot); }
@@ -433,6 +476,8 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg_in, int g, bool identi
         if (rend) grid.z = 1;       // the g frames of a persistence chain: one after the other inside each thread, the state in registers
         if (identity) {             // no warp behind the Gaussian chain: the blend and the commit only
             grid.y = (rows_out + 7) / 8;
+            c->plan.warp_frames = g;
+            plan_note(c->plan.warp, "k_warp_lean<%s,render,u8,rows=2,commit-only>", prom ? "f64" : "f32");
             if (prom) { CRTFX_LAUNCH((k_warp_lean<true, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
             else { CRTFX_LAUNCH((k_warp_lean<false, CRTFX_BLEND_RENDER, CRTFX_PIX_U8, 2, true>), grid, dim3(256), 0, s, pe.e0, pe.e1, c->kp, wg, g, g); }
             return;
@@ -442,6 +487,8 @@ void launch_warp_group(crtfx_ctx* c, const KWarpGroup& wg_in, int g, bool identi
         return;
     }
     grid.y = (rows_out + 3) / 4;    // the general kernel: 64 x 4 tiles (whole frames only)
+    c->plan.warp_frames = g;
+    plan_note(c->plan.warp, "k_warp<%s>", identity ? "commit-only" : "gather");
     if (chain && g > 1) {           // a persistence chain on the general kernel: its frames commit strictly in order (ref:1081-1105)
         for (int j = 0; j < g; ++j) {
             KWarpGroup one{};
@@ -465,6 +512,8 @@ void launch_split_blur(crtfx_ctx* c, const KFrame& kf, hipStream_t s) {
     const dim3 gr((W + SB_SPAN - 1) / SB_SPAN, (H + SB_RW - 1) / SB_RW), br(64 * SB_RW);
     // timed as kernel class 2 (the bloom passes in front of the pointwise kernel); the first launch carries the frame count
     ProfEv p0(c, 2, 1), p1(c, 2, 0);
+    plan_note(c->plan.blur, "%sk_sb_rows<%s>+%s", c->split_src_plane ? "k_sb_src+" : "", c->split_src_plane ? "plane" : pix_name(c->pix_fmt),
+              ((W & 3) == 0 && !c->split_src_plane) ? "k_sb_cols_lds" : ((W & 3) == 0 ? "k_sb_cols<4>" : "k_sb_cols<1>"));
     if (c->split_src_plane) {      // CRTFX_OPT_SPLIT_SRC_PLANE (A/B): the bloom source as its own plane first
         dim3 gs((W + 63) / 64, (H + 3) / 4);
         ProfEv ps(c, 2, 0);
@@ -522,6 +571,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
             const bool fold = !c->force_generic && !c->force_runtime_flags && (g0 == SF_FAST || g0 == SF_FAST_PIX) && !kf.overlay_before;
             const bool f16 = c->pix_fmt == CRTFX_PIX_F16;
             ProfEv ph(c, 2);
+            plan_note(c->plan.half, "k_half<%s,%s>", fold ? sf_name(g0) : "runtime", fold ? pix_name(c->pix_fmt) : "any");
             if (!fold) { CRTFX_LAUNCH((k_half<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
             else if (g0 == SF_FAST_PIX) {
                 if (f16) { CRTFX_LAUNCH((k_half<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kf); }
@@ -544,6 +594,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
         }
         else if (!c->force_generic) {      // any gate set, loads branch-free
             const bool one = !(fl & CRTFX_F_PIXELATE) && !((fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST));      // no load address depends on another load
+            plan_note(c->plan.point, "k_point_sel<%s,%s>", pix_name(c->pix_fmt), one ? "one-round" : "two-round");
             if (c->pix_fmt == CRTFX_PIX_F16) {
                 if (one) { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_F16, true>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
                 else { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_F16, false>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
@@ -552,7 +603,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
                 else { CRTFX_LAUNCH((k_point_sel<CRTFX_PIX_U8, false>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
             }
         }
-        else CRTFX_LAUNCH((k_point<SF_RUNTIME>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1);
+        else { plan_note(c->plan.point, "k_point<runtime>"); CRTFX_LAUNCH((k_point<SF_RUNTIME>), grid, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kf, k1); }
     }
     if (two) {
         KWarpGroup wg{};
@@ -794,7 +845,8 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
         const bool folded_plan = (gates_plan == SF_FULL || pix_fold_plan) && !c->force_runtime_flags && !((k.flags & CRTFX_F_NOISE) && k.grain > 1);
         // the render loop's full-chain launches with warp on park a pre-warp image -> k_phosphor_cc (launch_rr_group)
         const bool cc_plan = folded_plan && !pix_fold_plan && !c->no_cc && (k.flags & CRTFX_F_WARP) && use_cc(c, R);
-        const int cc_build = cc_plan ? ((!c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS) ? 2 : 1) : 0;
+        const bool cth_plan = folded_plan && !pix_fold_plan && (k.flags & CRTFX_F_WARP) && use_ct_half(c, R);
+        const int cc_build = cth_plan ? 2 : cc_plan ? ((!c->no_ct && c->pix_fmt == CRTFX_PIX_U8 && R <= CT_MAX_RADIUS) ? 2 : 1) : 0;
         GridPlan gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, 1, gcap, cc_build);
         if (c->opt_group >= 1 && c->opt_group <= MAX_GROUP) gp = plan_grid(H, W, R, c->pix_fmt, folded_plan, k.grade_lut != nullptr, c->opt_group, c->opt_group, cc_build);      // the planner's rows per block for the group size asked for
         if (c->opt_seg_rows >= NB) gp.seg = ((c->opt_seg_rows + NB - 1) / NB) * NB;
@@ -847,7 +899,7 @@ int crtfx_set_params(crtfx_ctx* c, const crtfx_params* p) {
                 if (src_end < H) {
                     row = c->band_row.back();
                     while (row < H && need[row] < src_end) ++row;
-                    row &= ~7;                                   // whole 8-row tiles
+                    row &= ~15;                                  // whole tiles of the tallest k_warp_lean shape (4 / WX waves x ROWS rows: 8 without a blend, 16 at most)
                     if (row < c->band_row.back()) row = c->band_row.back();
                 }
                 c->band_src.push_back(src_end); c->band_row.push_back(row);
@@ -878,6 +930,7 @@ int crtfx_apply_static(crtfx_ctx* c, const void* frame_dev, float* out_float_dev
     KOut ko{};
     ko.out_f32 = out_float_dev;
     ko.blend = CRTFX_BLEND_NONE;
+    c->plan = {};
     return run_chain(c, frame_dev, frame, ko, (hipStream_t)stream);
 }
 
@@ -894,6 +947,7 @@ int crtfx_apply(crtfx_ctx* c, const void* frame_dev, void* out_pix_dev, float* s
     ko.out_f32 = out_float_dev;
     ko.blend = blend;
     ko.p = persistence; ko.q = 1.0 - persistence;
+    c->plan = {};
     return run_chain(c, frame_dev, frame, ko, (hipStream_t)stream);
 }
 
@@ -970,6 +1024,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
     const bool warp = (fl & CRTFX_F_WARP) != 0;
     const bool gauss = (fl & CRTFX_F_BLOOM) && !(fl & CRTFX_F_BLOOM_FAST);
     const bool blend_on = persistence > 0.0;
+    c->plan = {};
 
     auto final_out = [&](int i) {
         KOut ko{};
@@ -1098,12 +1153,16 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (fastb) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
                     ProfEv ph(c, 2, g);
+                    plan_note(c->plan.half, "k_half_group<%s,%s>", lean ? sf_name(gates) : "runtime", lean ? pix_name(c->pix_fmt) : "any");
                     if (!lean) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
                     else if (pixelate) { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                     else { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                 }
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 ProfEv pe(c, 0, g);
+                c->plan.group = g;
+                if (lean) plan_note(c->plan.point, "k_point_lean_seq<%s,%s,%s>", sf_name(gates), pix_name(c->pix_fmt), blend_name(kg.o[0].blend == CRTFX_BLEND_RENDER ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE));
+                else plan_note(c->plan.point, "k_point_sel_seq<%s,%s>", pix_name(c->pix_fmt), (!(fl & CRTFX_F_PIXELATE) && !fastb) ? "one-round" : "two-round");
                 if (lean) {
                     dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
 #define CRTFX_SEQ(SFV, PIXV)                                                                                                                             \
@@ -1209,6 +1268,33 @@ int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, cons
             }
             row_out[(size_t)x * cn + ch] = s;
         }
+    return CRTFX_OK;
+}
+
+int crtfx_last_plan(crtfx_ctx* c, char* buf, size_t n) {
+    if (!c || !buf || n == 0) return CRTFX_E_INVALID;
+    const crtfx_ctx::Plan& p = c->plan;
+    size_t o = 0;
+    buf[0] = 0;
+    auto add = [&](const char* key, const char* val) {
+        if (!val[0] || o + 1 >= n) return;
+        const int w = snprintf(buf + o, n - o, "%s%s=%s", o ? ";" : "", key, val);
+        if (w > 0) o = (o + (size_t)w < n) ? o + (size_t)w : n - 1;
+    };
+    char num[32];
+    add("phosphor", p.phosphor);
+    add("blur", p.blur);
+    add("half", p.half);
+    add("point", p.point);
+    if (p.phosphor[0] || p.point[0]) {
+        snprintf(num, sizeof num, "%d", p.group); add("group", num);
+        if (p.phosphor[0]) {
+            snprintf(num, sizeof num, "%d", p.seg_rows); add("seg_rows", num);
+            snprintf(num, sizeof num, "%d", c->group_max); add("group_max", num);      // the planner's frames per grid (a batch's last group may be shorter)
+        }
+    }
+    add("warp", p.warp);
+    if (p.warp[0]) { snprintf(num, sizeof num, "%d", p.warp_frames); add("warp_frames", num); }
     return CRTFX_OK;
 }
 

@@ -375,7 +375,16 @@ __device__ __forceinline__ uint32_t quant_u8x3(float v0, float v1, float v2) {
 }
 
 // a15 for half frames: |x*255| narrowed to half (convertScaleAbs without the integer rounding)
-__device__ __forceinline__ uint32_t quant_f16(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)fabsf(v * 255.0f)); }   // RNE narrowing
+// TWO roundings, as numpy's `np.abs(x.astype(float32) * float32(255)).astype(float16)`: the float32 product, then RNE to half.  Written as
+// (_Float16)fabsf(v * 255.0f) hipcc is free to emit v_fma_mixlo_f16 (product and narrowing in one rounding) in one kernel and v_mul_f32 +
+// v_cvt_f16_f32 in another: the builds then differ by one half ulp wherever the float32 product is an exact tie (round 5: the general
+// kernels against the lean ones, ~1 sample in 10^5, always the R channel).  The conversion is therefore pinned as its own instruction.
+__device__ __forceinline__ uint32_t quant_f16(float v) {
+    const float s = fabsf(v * 255.0f);
+    uint32_t h;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(s));
+    return h & 0xFFFFu;
+}
 
 struct PackedPix { uint32_t lo, hi; };   // uint8: lo = r | g<<8 | b<<16.  half: lo = r | g<<16, hi = b.
 

@@ -613,6 +613,7 @@ typedef __attribute__((address_space(3))) float lds_f32_t;
 typedef __attribute__((address_space(3))) double lds_f64_t;
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 #define LDS_AT(T, off) (*(T*)(uintptr_t)(uint32_t)(off))
 

@@ -55,20 +55,29 @@ namespace crtfx {
 __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3 + 5) / 4 + 1; }
 // the centre ring: CT_RING_ROWS rows (a power of two >= R + 2 NB for every radius this kernel serves) of TW dwords
 constexpr int CT_RING_ROWS = 32;
-__host__ __device__ constexpr int ct_ring_words(int R) { return CT_RING_ROWS * TW; }
-// LDS words: staging, one H-row tile, two tables, the centre ring, vignette tile (f64), two grain tiles (f32): 38.8 KB at R = 9
-__host__ __device__ constexpr int ct_lds_words(int R) {
-    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R) + NB * TW * 2 + 2 * NB * TW;
+// half frames (PIX = 1): no ring.  A sample is two bytes, so a ring row of frame-row windows would be 512 bytes and the ring 16 KB (three blocks
+// per CU).  Instead the A phase parks the window QWORDS (four half samples each) of the trip's eight rows in a one-trip RAW TILE (8 rows of 64
+// qwords = 4 KB) and each consumer thread — which owns one float of the strip row in the V pass and the tail — keeps the raw centre samples of
+// its float for the R + NB rows between staging and use in a REGISTER WINDOW of packed halves ((R + NB + 1) / 2 VGPRs: 9 at R = 9), next to the
+// V pass's row window: 34.8 KB of LDS at R = 9, four blocks per CU.
+__host__ __device__ constexpr int ct_ring_words(int R, int pix = 0) { return pix ? NB * TW * 2 : CT_RING_ROWS * TW; }
+// LDS words: staging, one H-row tile, two tables, the centre ring / raw tile, vignette tile (f64), two grain tiles (f32): 38.8 KB at R = 9 (uint8)
+__host__ __device__ constexpr int ct_lds_words(int R, int pix = 0) {
+    return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R, pix) + NB * TW * 2 + 2 * NB * TW;
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 15 ? CT_WAVES : (R <= 20 ? 3 : 2); }
+#ifndef CT_HALF_MAX_RADIUS
+#define CT_HALF_MAX_RADIUS 12      // the half build's radii (crtfx_rr.hip, launch_rr_group): the centre window takes (R + 9) / 2 VGPRs more than the uint8 build
+#endif
 
-template <int RT>
+template <int RT, int PIX = 0>
 __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KParams Pin, KGroup G, int seg_rows) {
     const KFrame F = G.f[blockIdx.z];
     const KOut O = G.o[blockIdx.z];
     KParams P = Pin;
     P.flags = SF_FULL;
-    P.pix = 0;
+    P.pix = PIX;
+    constexpr bool HALF = PIX != 0;
     extern __shared__ float4 smem4[];
     float* smem = reinterpret_cast<float*>(smem4);
     constexpr int R = RT;
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     // modulo of the (per-lane) write row is a mask.  A row holds the 64 packed centre pixels (byte-wise path) or the dwords of the frame-row
     // window that overlap the centre pixels' bytes (at most 62 for |d| <= 8; dword 63 takes the window's other dwords)
     constexpr int RSH = R % NB;
-    static_assert(CR <= CT_RING_ROWS && (CT_RING_ROWS & (CT_RING_ROWS - 1)) == 0, "the centre ring holds R + 2 NB rows in a power-of-two ring");
+    static_assert(HALF || (CR <= CT_RING_ROWS && (CT_RING_ROWS & (CT_RING_ROWS - 1)) == 0), "the centre ring holds R + 2 NB rows in a power-of-two ring");
     constexpr uint32_t RING_MASK = (uint32_t)(CT_RING_ROWS * TW * 4 - 1);
     constexpr int NQF = (NB * NDMAX + 63) / 64;
     constexpr int FO = (NQF + 4) / 5;                    // ... of each consumer wave (items wave, wave + 3, ...)
@@ -99,9 +108,10 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     constexpr uint32_t HROW_B = STG_B + NB * 3 * SWS * 4;                    // [NB][CC_HROW] float     H rows, interleaved like the image row (x, channel)
     constexpr uint32_t LUT_B = HROW_B + HT * 4;                              // [2][LUT_STRIDE] float   composite tables T_m0, T_m1 — or lut_g, lut_inv
     constexpr uint32_t RING_B = LUT_B + 2 * LUT_STRIDE * 4;                  // [32][TW] dword          centre ring: frame-row window dwords (fast path) / packed centre pixels (byte-wise path)
-    constexpr uint32_t GVIG_B = RING_B + ct_ring_words(R) * 4;               // [NB][TW] double         vignette gain tile
+                                                                             // half: [NB][TW] qword    raw tile of this trip's rows: window qwords / the centre pixels' 3 x uint16
+    constexpr uint32_t GVIG_B = RING_B + ct_ring_words(R, PIX) * 4;          // [NB][TW] double         vignette gain tile
     constexpr uint32_t GN_B = GVIG_B + NB * TW * 8;                          // [2][NB][TW] float       grain tiles
-    static_assert(GN_B + 2 * NB * TW * 4 == (uint32_t)ct_lds_words(R) * 4, "LDS map and ct_lds_words disagree");
+    static_assert(GN_B + 2 * NB * TW * 4 == (uint32_t)ct_lds_words(R, PIX) * 4, "LDS map and ct_lds_words disagree");
     static_assert(SWS - SWP >= 4, "the dword A phase parks the bytes it does not stage in the four pad floats behind a staging plane");
     float* stg = smem;
     float* hrow = smem + HROW_B / 4;
@@ -164,7 +174,10 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     // correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no f / 255 lies that close to a
     // rounding boundary: its bits beyond the mantissa repeat f's own eight; checked with exact rationals on the host, and
     // against k_phosphor_cc's table of IEEE quotients on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
+    // (half frames: float(h) / 255.0f by norm_px's corrected reciprocal product — the IEEE quotient for every finite half, and k_phosphor_rr's
+    // own expression, so that the builds agree on non-finite samples too)
     auto a1 = [&](uint32_t u) -> float {
+        if constexpr (HALF) return norm_px(CRTFX_PIX_F16, u);
         const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f);
     };
     // two bytes at once: the multiply and the fma as ONE packed instruction each (v_pk_mul_f32, v_pk_fma_f32) — the same two roundings per byte
@@ -184,19 +197,26 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int y = min(max(hb + it / SWP, 0), H - 1);                          // BORDER_REPLICATE
         const uint32_t ro = (uint32_t)__umul24((uint32_t)y, row_elems);
-        return load_raw(0, F.in, ro + o_r, ro + o_g, ro + o_b);
+        return load_raw(PIX, F.in, ro + o_r, ro + o_g, ro + o_b);
     };
     auto a_write = [&](int q, uint32_t crow0s, RawRGB v) {      // crow0s: byte offset of the ring row of this trip's first staged row, before the shift
         const int it = min((q << 6) + lane, NB * SWP - 1);
         const int j = it / SWP, i = it - j * SWP;
-        if (i >= pad && i < pad + TW)                      // a centre pixel: parked as packed bytes for the tail
+        if (i >= pad && i < pad + TW) {                    // a centre pixel: parked as packed bytes for the tail (half: its three samples in the raw tile)
+            if constexpr (HALF) {
+                const uint32_t cb = RING_B + (uint32_t)(j * TW * 8 + (i - pad) * 6);
+                LDS_AT(lds_u16_t, cb) = (uint16_t)v.r; LDS_AT(lds_u16_t, cb + 2u) = (uint16_t)v.g; LDS_AT(lds_u16_t, cb + 4u) = (uint16_t)v.b;
+            } else
             LDS_AT(lds_u32_t, RING_B + ((crow0s + (uint32_t)(((j + RSH) * TW + (i - pad)) * 4)) & RING_MASK)) = v.r | (v.g << 8) | (v.b << 16);
+        }
         float* sp = stg + (j * 3) * SWS + i;
         sp[0] = a1(v.r); sp[SWS] = a1(v.g); sp[2 * SWS] = a1(v.b);
     };
     // -- dword A phase: item = (row j, dword k of the row window); block-invariant per lane: the dword's byte offset in a frame row,
-    // its row, and the staging slots of its four bytes (a byte that belongs to no staged sample goes to a pad float behind its plane)
-    struct FItem { uint32_t ld, j, s[4], rq; };       // rq: (row j + RSH) * 256 + 4 * (its dword of the ring row)
+    // its row, and the staging slots of its four bytes (a byte that belongs to no staged sample goes to a pad float behind its plane).
+    // Half frames: everything below counts SAMPLES, the unit of four is a qword, and the raw unit goes to the one-trip raw tile.
+    using FRaw = std::conditional_t<HALF, uint2, uint32_t>;
+    struct FItem { uint32_t ld, j, s[4], rq; };       // rq: (row j + RSH) * 256 + 4 * (its dword of the ring row); half: row j * 512 + 8 * (its qword of the tile row)
     const int kc_lo = (int)(((uint32_t)(x0 - aab) * 3u - a_lo) >> 2), kc_hi = (int)(((uint32_t)(x0 + TW - 1 + aab) * 3u + 2u - a_lo) >> 2);      // window dwords holding centre bytes
     auto f_setup = [&](int q) -> FItem {
         FItem it;
@@ -204,7 +224,8 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         const int j = idx / ND, k = idx - j * ND;
         it.ld = a_lo + 4u * (uint32_t)k;
         it.j = (uint32_t)j;
-        it.rq = (uint32_t)((j + RSH) * TW * 4) + 4u * (uint32_t)((k >= kc_lo && k <= kc_hi) ? k - kc_lo : TW - 1);
+        if constexpr (HALF) it.rq = (uint32_t)(j * TW * 8) + 8u * (uint32_t)((k >= kc_lo && k <= kc_hi) ? k - kc_lo : TW - 1);
+        else it.rq = (uint32_t)((j + RSH) * TW * 4) + 4u * (uint32_t)((k >= kc_lo && k <= kc_hi) ? k - kc_lo : TW - 1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int b = (int)it.ld + e;                  // byte of the frame row
@@ -215,15 +236,22 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
         }
         return it;
     };
-    auto f_load = [&](const FItem& it, int hb) -> uint32_t {
+    auto f_load = [&](const FItem& it, int hb) -> FRaw {
         const int y = min(max(hb + (int)it.j, 0), H - 1);                         // BORDER_REPLICATE
-        return *reinterpret_cast<const uint32_t*>(F.in + ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));
+        if constexpr (HALF) return *reinterpret_cast<const uint2*>(F.in + 2u * ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));      // frame bytes < 2^32 (launch_rr_group)
+        else return *reinterpret_cast<const uint32_t*>(F.in + ((uint32_t)__umul24((uint32_t)y, row_elems) + it.ld));
     };
-    auto f_write = [&](const FItem& it, uint32_t crow0s, uint32_t d) {
-        LDS_AT(lds_u32_t, RING_B + ((crow0s + it.rq) & RING_MASK)) = d;      // the raw window dword
+    auto f_write = [&](const FItem& it, uint32_t crow0s, FRaw d) {
         float o[4];
-        a1x2(d & 255u, (d >> 8) & 255u, o[0], o[1]);
-        a1x2((d >> 16) & 255u, d >> 24, o[2], o[3]);
+        if constexpr (HALF) {
+            LDS_AT(lds_u64_t, RING_B + it.rq) = (unsigned long long)d.x | ((unsigned long long)d.y << 32);      // the raw window qword
+            a1x2(d.x & 0xFFFFu, d.x >> 16, o[0], o[1]);
+            a1x2(d.y & 0xFFFFu, d.y >> 16, o[2], o[3]);
+        } else {
+            LDS_AT(lds_u32_t, RING_B + ((crow0s + it.rq) & RING_MASK)) = d;      // the raw window dword
+            a1x2(d & 255u, (d >> 8) & 255u, o[0], o[1]);
+            a1x2((d >> 16) & 255u, d >> 24, o[2], o[3]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) LDS_AT(lds_f32_t, it.s[e]) = o[e];
     };
@@ -282,8 +310,35 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             const __amdgpu_buffer_rsrc_t scan_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(F.scan_row), 0, H * 4, 0x00020000);
             // this float's centre byte inside a ring row: FAST — its byte of the frame-row window (a2: R from column x - d, B from
             // x + d; the window is inside the frame, no wrap); else byte fch of packed pixel fcol
-            const uint32_t cpl = FAST ? (uint32_t)((x0 + fcol + (fch == 0 ? -P.ab : (fch == 2 ? P.ab : 0))) * 3 + fch) - a_lo - 4u * (uint32_t)kc_lo
-                                      : (uint32_t)(fcol * 4 + fch);
+            const uint32_t cpl = FAST ? ((uint32_t)((x0 + fcol + (fch == 0 ? -P.ab : (fch == 2 ? P.ab : 0))) * 3 + fch) - a_lo - 4u * (uint32_t)kc_lo) * (HALF ? 2u : 1u)
+                                      : (HALF ? (uint32_t)(fcol * 6 + fch * 2) : (uint32_t)(fcol * 4 + fch));
+            // half frames: the raw centre samples of this float, rows yb .. yb + R + NB - 1 (yb = the next trip's first output row), packed two
+            // per VGPR: element i = cw[i >> 1], half i & 1.  A trip takes elements 0 .. 7 (phase 1), moves the rest down by eight and appends
+            // the eight rows the A phase has just parked in the raw tile (phase 2).
+            constexpr int NW = R + NB;
+            uint32_t cw[HALF ? (NW + 1) / 2 : 1];
+#pragma unroll
+            for (int i = 0; i < (HALF ? (NW + 1) / 2 : 1); ++i) cw[i] = 0u;
+            auto cw_take = [&](float (&v)[NB]) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) v[j] = a1((j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xFFFFu);
+            };
+            auto cw_shift = [&]() {
+#pragma unroll
+                for (int i = 0; i < (R + 1) / 2; ++i) cw[i] = cw[i + NB / 2];
+            };
+            auto cw_append = [&]() {
+                uint32_t hs[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) hs[j] = (uint32_t)LDS_AT(lds_u16_t, RING_B + (uint32_t)(j * TW * 8) + cpl);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int i = R + j;
+                    if ((i & 1) == 0 && j + 1 < NB) cw[i >> 1] = hs[j] | (hs[j + 1] << 16);
+                    else if ((i & 1) == 0) cw[i >> 1] = hs[j];      // the window's last element: its upper half is unused
+                    else if (j == 0) cw[i >> 1] = (cw[i >> 1] & 0xFFFFu) | (hs[0] << 16);      // R odd: element R shares its VGPR with element R - 1
+                }
+            };
             f32x2 win2[L / 2];
 #pragma unroll
             for (int i = 0; i < L / 2; ++i) win2[i] = f32x2{0.0f, 0.0f};
@@ -340,7 +395,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             };
             // ---- A items of this wave ----
             FItem fit[FAST ? FO : 1];
-            uint32_t fraw[FAST ? FO : 1];
+            FRaw fraw[FAST ? FO : 1];
             uint32_t offr[FAST ? 1 : AO], offg[FAST ? 1 : AO], offb[FAST ? 1 : AO];
             RawRGB raw[FAST ? 1 : AO];
             if constexpr (FAST) {
@@ -390,7 +445,8 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 // are dropped by the buffer's range check), so the taps and the tail are skipped — a wave-uniform test
                 const bool warm = CT_WARM_SKIP && yb + NB <= y_begin;
                 float v[NB];
-                if (!warm) centre(c2row0, v);               // issued first: the LDS round trip runs under the V pass
+                if constexpr (HALF) { if (!warm) cw_take(v); cw_shift(); }
+                else if (!warm) centre(c2row0, v);          // issued first: the LDS round trip runs under the V pass
                 {
                     float blur[NB];
                     CC_PRIO(CC_P_VH);
@@ -412,6 +468,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 STAMP(1);
                 // ---- phase 2: C2 of block n-1 (output rows yb + j), stage by stage over the eight rows ----
                 CC_PRIO(CC_P_C2);
+                if constexpr (HALF) cw_append();
                 const uint32_t gt_b = GN_B + (uint32_t)(((n & 1) ^ 1) * NB * TW * 4) + gcol4;
                 if (!warm) {
                     float gnv[NB];
@@ -451,7 +508,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
                 const int yb = hb - NB - R;
                 const uint32_t slv = scan_load(yb);
                 float v[NB], blur[NB];
-                centre(c2row0, v);
+                if constexpr (HALF) cw_take(v); else centre(c2row0, v);
                 v_pass(blur, false);
                 __syncthreads();
                 const float* gt = gn + ((n_iter & 1) ^ 1) * NB * TW;
@@ -480,7 +537,7 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
             const double cnx2 = P.vig_nx2[min(xg, W - 1)];
             constexpr int NH = FAST ? (FH > 0 ? FH : 1) : (A3 > 0 ? A3 : 1);
             FItem fit[FAST ? NH : 1];
-            uint32_t fraw[FAST ? NH : 1];
+            FRaw fraw[FAST ? NH : 1];
             uint32_t offr[FAST ? 1 : NH], offg[FAST ? 1 : NH], offb[FAST ? 1 : NH];
             RawRGB raw[FAST ? 1 : NH];
             if constexpr (FAST) {

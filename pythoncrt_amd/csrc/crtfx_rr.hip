@@ -33,6 +33,12 @@ void CRTFX_CAT(rr_launch_, RR_R)(const KParams& kp, const KGroup& kg, int seg_ro
         return;
     }
 #endif
+#if RR_R <= CT_HALF_MAX_RADIUS
+    if (variant == 7) {     // as variant 6 for half frames: qword loads, a one-trip raw tile, the centre samples in a register window
+        CRTFX_LAUNCH((k_phosphor_ct<RR_R, 1>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);
+        return;
+    }
+#endif
 #if RR_R <= 30
     if (variant == 4) {     // full-chain gates, pre-warp image out: the column-owner kernel (uint8 frames)
         CRTFX_LAUNCH((k_phosphor_cc<RR_R, 0>), grid, dim3(RR_THREADS), lds, s, e0, e1, kp, kg, seg_rows);

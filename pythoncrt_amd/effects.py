@@ -290,6 +290,17 @@ class Engine:
         except Exception:
             pass
 
+    def last_plan(self) -> dict:
+        """crtfx_last_plan as a dict: which build of each kernel class the last apply / process_batch call launched."""
+        buf = ctypes.create_string_buffer(512)
+        _lib.check(self.lib, self.ctx, self.lib.crtfx_last_plan(self.ctx, buf, len(buf)))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, _, v = item.partition("=")
+                out[k] = int(v) if v.lstrip("-").isdigit() else v
+        return out
+
     # -- params ------------------------------------------------------------------------
     def set_params(self, s: "Settings"):
         key = s.key()

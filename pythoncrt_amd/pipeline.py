@@ -116,7 +116,7 @@ class FramePipeline:
         self.overlay_after = bool(text_overlay_after)
         self.noise_seed = int(noise_seed)
         self.dtype = dtype                  # torch.uint8, or torch.float16 (half frames on the 0..255 scale)
-        self._glitch_stage = {}             # (frames, rows, segments) -> two [pinned int32 block, upload event] pairs (frame_records)
+        self._glitch_stage = {}             # (frames, rows, segments) -> {"slots": two [pinned int32 block, upload event] pairs, "turn": which one is next} (frame_records)
         self.engine = Engine(device, h, w, _lib.PIX_F16 if dtype == torch.float16 else _lib.PIX_U8)
         self.static = settings.static_settings(self.h, self.w)
         self.engine.set_params(self.static)
@@ -162,13 +162,14 @@ class FramePipeline:
                 rows, cols = drawn[0][1].shape
                 # two pinned staging blocks per shape, reused in turn (a fresh hipHostMalloc per batch made one step in three take 15-80 ms
                 # instead of 6: profiles/r04_cli_scan.txt); a block is rewritten only once the upload that last read it has completed
-                slots = self._glitch_stage.setdefault((n, rows, cols), [])
+                shape = self._glitch_stage.setdefault((n, rows, cols), {"slots": [], "turn": 0})      # the turn is per shape: two shapes that
+                slots = shape["slots"]                                                                 # alternate (a full batch and a short last one) must not pin each other to one slot
                 if len(slots) < 2:
                     slots.append([torch.empty((n, rows, cols), dtype=torch.int32).pin_memory(), None])
                     host, ev = slots[-1][0], None
                     k = len(slots) - 1
                 else:
-                    k = self._glitch_turn = (getattr(self, "_glitch_turn", 0) + 1) & 1
+                    k = shape["turn"] = (shape["turn"] + 1) & 1
                     host, ev = slots[k]
                 if ev is not None:
                     ev.synchronize()
@@ -248,6 +249,11 @@ class FramePipeline:
         _lib.check(self.lib, self.engine.ctx, rc)
         self._hold = hold                         # keep per-frame tables (scanline gains included) alive until the next run replaces them
         return out, (state if p > 0.0 else None)
+
+    def plan(self) -> dict:
+        """Which kernel builds the last run() landed on (crtfx_last_plan): {"phosphor": "k_phosphor_ct<9,u8>", "group": 2, "seg_rows": 256,
+        "warp": "k_warp_lean<...,plain>", ...}."""
+        return self.engine.last_plan()
 
     # ---- profiling hooks (HIP events recorded by the library on the launch stream) ----------
     def profile(self, on):
@@ -334,11 +340,11 @@ class GpuShardEngine:
         final.copy_(st)                                         # its own buffer per slot: the next round's scan reuses self.state while this one travels
         return _LocalStates(local[:k], final, n), out[:n]
 
-    def sequential_scan(self, frames, first_index, state):
+    def sequential_scan(self, frames, first_index, state, slot: int = 0):
         """world 1: the chunk continues from the true state of the previous one (None at the start of the clip)."""
         n = frames.shape[0]
         recs = self.records.pop(first_index, None)
-        out, state = self.pipe.run(frames, first_index=first_index, state=state, out=self.out[:n], records=recs)
+        out, state = self.pipe.run(frames, first_index=first_index, state=state, out=self.out_slots[slot % self.slots][:n], records=recs)
         return out, state
 
     def correct(self, local, carry, p, out):

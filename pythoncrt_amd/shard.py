@@ -393,17 +393,21 @@ class ShardedRender:
         has_frames = frames is not None and frames.shape[0] > 0 and r < a
         c = sh.chunk_of(round_index)
         first = c * sh.chunk
+        # an engine with several output slots (GpuShardEngine(slots=3) of the CLI, whose download stream may still be reading round r - 1's
+        # frames) gets a fresh slot every round in THIS schedule too — the default over RCCL, and what every p = 0 render runs
+        nslots = int(getattr(self.engine, "slots", 1))
+        slot_kw = {"slot": round_index % nslots} if nslots >= 2 else {}
         if w == 1 and p > 0.0 and hasattr(self.engine, "sequential_scan"):
             # one rank owns consecutive chunks: carry the state itself (the reference's in-order loop, ref:1081-1105),
             # no zero-state scan and no correction pass
-            out, self.carry_next_round = self.engine.sequential_scan(frames, first, None if c == 0 else self.carry_next_round)
+            out, self.carry_next_round = self.engine.sequential_scan(frames, first, None if c == 0 else self.carry_next_round, **slot_kw)
             return out
         if not has_frames:
             # a partial last round: nothing to render here, and nobody downstream waits for this rank's state
             # (the exchange below is only between ranks < active, and there is no next round to seed)
             return None
         e0 = self._ev(frames)
-        local, out = self.engine.local_scan(frames, first, clip_start=(c == 0))
+        local, out = self.engine.local_scan(frames, first, clip_start=(c == 0), **slot_kw)
         e1 = self._ev(frames)
         if p <= 0.0:
             return out

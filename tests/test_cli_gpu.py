@@ -164,6 +164,43 @@ def test_sharded_cli_two_ranks(pc, tmp_path, persistence, n_frames):
         assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
 
 
+@pytest.mark.parametrize("persistence", ["0", "0.5"])
+def test_sharded_cli_synchronous_schedule(pc, tmp_path, persistence):
+    """The schedule the sharded CLI runs over RCCL by default, and for every render without persistence: ShardedRender.run_round, one round
+    finished per call, its frames downloaded asynchronously while the next round is scanned.  Every round must write its own output slot
+    (round 4's advisor finding: run_round always wrote slot 0, so round r + 1's scan could overwrite frames round r's download was still
+    reading, and the small-frame test passed by timing).  Here every download is held back by 30 ms of GPU time
+    (CRTFX_TEST_DOWNLOAD_DELAY_MS): a missing slot rotation or ordering gives wrong bytes every time."""
+    import socket
+    import subprocess
+    import sys
+    from pythoncrt_amd import cli
+    h, w, n_frames = 72, 128, 17
+    frames = clip(n_frames, h, w, 19)
+    src = tmp_path / "in.rgb"
+    src.write_bytes(frames.tobytes())
+    flags = ["--width", str(w), "--height", str(h), "--fps", "30", "--batch", "2", "--noise-seed", "7", "--persistence", persistence,
+             "--no-fast-bloom", "--bloom-sigma", "1.2", "--warp-strength", "0.15", "--pixel-size", "1"]
+    one = tmp_path / "one.rgb"
+    assert cli.main(["--input", str(src), "--output", str(one)] + flags) == 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = tmp_path / "two.rgb"
+    env = dict(os.environ, CRTFX_DIST_BACKEND="gloo", CRTFX_SHARD_OVERLAP="0", CRTFX_TEST_DOWNLOAD_DELAY_MS="30",
+               PYTHONPATH=os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "pythoncrt_amd.cli", "--input", str(src), "--output", str(two)] + flags
+    r = subprocess.run(cmd, env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = np.frombuffer(one.read_bytes(), dtype=np.uint8)
+    b = np.frombuffer(two.read_bytes(), dtype=np.uint8)
+    assert a.size == b.size == frames.size
+    if persistence == "0":
+        assert np.array_equal(a, b)
+    else:
+        d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
+
+
 def test_c_abi_consumer(pc, tmp_path):
     """examples/crtfx_c_abi.cpp: a program that uses only include/crtfx.h, libcrtfx.so and the HIP runtime (no Python
     or torch in its call path; it builds the vignette and warp axis tables itself) renders the same bytes as the Python

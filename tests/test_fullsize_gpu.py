@@ -113,6 +113,66 @@ def test_fp16_wide_frames_against_oracle(dev, ab, hw, sigma):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("ab,hw,sigma", [(1, (40, 448), 3.0), (0, (33, 704), 1.2), (-3, (40, 448), 3.0), (8, (24, 640), 4.0), (-8, (40, 320), 3.0), (2, (60, 256), 0.4),
+                                         (1, (30, 449), 3.0), (1, (40, 450), 3.0), (-1, (37, 708), 2.0), (5, (1100, 128), 3.3), (1, (520, 1024), 3.0)])
+def test_fp16_column_owner_kernel(dev, ab, hw, sigma, monkeypatch):
+    """Round 5: half frames that park a pre-warp image (warp on) run k_phosphor_ct<R, half> — frame-row windows as aligned qwords, the raw units of a
+    trip in a one-trip LDS tile, each consumer thread's centre samples in a register window of packed halves.  Every aberration sign and size,
+    radii 1 .. 12, interior / edge / partial strips, a width that is not a multiple of four (all strips on the per-sample A phase), an odd
+    width (frames of a batch off a qword: the register-window kernel), tall frames (several row segments, window-fill trips), and a frame that does not start on a qword (falls back to k_phosphor_rr):
+    (1) bit-identical frames to the register-window kernel (NO_CT), its runtime-gate instantiation and the generic LDS-ring kernel;
+    (2) the oracle at the bar of the 8K test."""
+    import dataclasses
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    h, w = hw
+    rs = dataclasses.replace(baseline_config(5)[0], aberration_px=ab, bloom_sigma=sigma)
+    assert rs.warp_strength == 0.15
+    first, seed, n = 4, 99, 3
+    rng = np.random.default_rng(900 + ab)
+    frames = (rng.random((n, h, w, 3), dtype=np.float32) * 255.0).astype(np.float16)
+    frames[0, :, : w // 2] = frames[0, :1, :1]                       # flat areas beside noise
+    frames[1, h // 3] = np.float16(255.0)
+    frames[2, :, ::7] = np.float16(0.0)
+    dframes = torch.from_numpy(frames).to(dev)
+    outs = {}
+    for name, opts in (("ct", {}), ("rr", {"NO_CT": 1}), ("runtime", {"FORCE_RUNTIME_FLAGS": 1}), ("generic", {"FORCE_GENERIC": 1}), ("ct_seg", {"SEG_ROWS": 24, "GROUP": 2})):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+        effects._tls.engines = {}
+        pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed, dtype=torch.float16)
+        out, _ = pipe.run(dframes, first_index=first)
+        outs[name] = out.clone()
+        if name == "ct":
+            # (a frame size that is not a multiple of 8 bytes — 30 x 449 — puts the batch's second frame off a qword: the whole group falls back)
+            want = "k_phosphor_ct<%d,half>" % rs_radius(sigma) if (h * w * 6) % 8 == 0 else "k_phosphor_rr<"
+            assert pipe.plan().get("phosphor", "").startswith(want), pipe.plan()
+            planes = _export_planes(pipe, seed, first, n, h, w)
+            # two bytes into an allocation: not on a qword -> the register-window kernel, the same bits
+            raw = torch.zeros(frames.size * 2 + 8, dtype=torch.uint8, device=dev)
+            shifted = raw[2:2 + frames.size * 2].view(torch.float16).view(n, h, w, 3)
+            shifted.copy_(dframes)
+            out2, _ = pipe.run(shifted, first_index=first)
+            assert pipe.plan().get("phosphor", "").startswith("k_phosphor_rr<"), pipe.plan()
+            assert torch.equal(out2, out)
+        elif name == "rr":
+            assert pipe.plan().get("phosphor", "").startswith("k_phosphor_rr<"), pipe.plan()
+    effects._tls.engines = {}
+    for name in ("rr", "runtime", "generic", "ct_seg"):
+        assert torch.equal(outs["ct"], outs[name]), name
+    got = outs["ct"].cpu().numpy()
+    params = {k: getattr(rs, k) for k in PARAM_KEYS}
+    for i in range(n if h * w < 200000 else 1):
+        _, st = orc.process_frames([frames[i]], params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                   rs.vignette_strength, noise_planes=[planes[i]], first_index=first + i)
+        exp16 = np.abs(st.astype(np.float32) * np.float32(255.0)).astype(np.float16)
+        diff = np.abs(got[i].astype(np.float32) - exp16.astype(np.float32))
+        assert diff.max() <= 0.125 and (got[i] != exp16).mean() < 5e-3, (ab, hw, i, float(diff.max()), float((got[i] != exp16).mean()))
+
+
+def rs_radius(sigma):
+    return int(round(3 * sigma))
+
+
 @pytest.mark.parametrize("speed", [30.0, 31.7])       # integer phases (one shared table, regenerated far ahead) / fractional phases (one table per batch)
 def test_records_built_ahead_of_their_launches(dev, speed):
     """frame_records() for several batches BEFORE the first of them runs (bench.py --tables-outside, GpuShardEngine.records):
