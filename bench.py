@@ -99,24 +99,87 @@ def copy_ceiling(device):
     return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def mall_ceiling(frames_per_launch, h=2160):
-    """GB/s (float32 source + uint8 output bytes) at which a hand-written stream reads a launch group's pre-warp images back RIGHT AFTER they
-    were written, from the committed run of tools/ubench/mall_copy.hip (profiles/r04_mall_copy.txt; 'x3' = one 12-byte pixel per lane):
-    k_warp's yardstick — its source is kept under the 256 MB Infinity Cache on purpose, so the HBM-sized copy of `copy_ceiling` is the
-    wrong one for it.  A committed measurement of the same chip model, not of this box: labelled as such."""
+MALL_COPY_EXE = os.path.join(ROOT, "build", "ubench", "mall_copy")      # tools/ubench/mall_copy.hip, compiled by __graft_entry__.build()
+
+
+def _mall_rows(text, want):
     import re
+    rows = {}
+    for line in text.splitlines():
+        m = re.match(r"(\d+) frame\(s\).*?\b(x4|x3|tap4|row2)\s+([\d.]+) us\s+(\d+) GB/s", line)
+        if m and int(m.group(1)) == want:
+            rows[m.group(2)] = {"us_per_group": float(m.group(3)), "gbs": float(m.group(4))}
+    return rows
+
+
+def mall_ceiling(frames_per_launch, h, w):
+    """GB/s (float32 source + uint8 output bytes) at which a hand-written stream reads a launch group's pre-warp images back RIGHT AFTER they
+    were written ('x3' = one 12-byte pixel per lane; 'tap4' = k_warp_lean's four-tap access shape with no arithmetic): k_warp's yardstick — its
+    source is kept under the 256 MB Infinity Cache on purpose, so the HBM-sized copy of `copy_ceiling` is the wrong one for it.  MEASURED ON THIS
+    BOX, before the timed region: tools/ubench/mall_copy.hip (built in-tree by build()) run as a child process for this frame size and group
+    (~1 s).  None when the program is not built or fails — the committed figure of another box is then only under `reference_figures`."""
+    import subprocess
+    want = max(1, int(round(frames_per_launch)))
+    if not os.access(MALL_COPY_EXE, os.X_OK):
+        return None
+    try:
+        r = subprocess.run([MALL_COPY_EXE, str(int(w)), str(int(h)), str(want)], capture_output=True, text=True, timeout=60)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    rows = _mall_rows(r.stdout, want) if r.returncode == 0 else {}
+    if "x3" not in rows:
+        return None
+    return {"gbs": rows["x3"]["gbs"], "us_per_group": rows["x3"]["us_per_group"], "frames": want,
+            "tap4_us_per_group": rows.get("tap4", {}).get("us_per_group"),
+            "source": "tools/ubench/mall_copy.hip run on this box before the timed region"}
+
+
+def mall_ceiling_committed(frames_per_launch, h):
+    """The same figure from a committed run on ANOTHER box of the same chip model (profiles/r04_mall_copy*.txt): a reference figure, kept out
+    of `roofline`."""
     name = {2160: "r04_mall_copy.txt", 1080: "r04_mall_copy_1080p.txt"}.get(int(h))
     if name is None:
         return None
-    path = os.path.join(ROOT, "profiles", name)
     want = max(1, int(round(frames_per_launch)))
     try:
-        for line in open(path):
-            m = re.match(r"(\d+) frame\(s\).*\bx3\s+([\d.]+) us\s+(\d+) GB/s", line)
-            if m and int(m.group(1)) == want:
-                return {"gbs": float(m.group(3)), "us_per_group": float(m.group(2)), "frames": want, "source": f"profiles/{name} (tools/ubench/mall_copy.hip, committed run)"}
+        rows = _mall_rows(open(os.path.join(ROOT, "profiles", name)).read(), want)
     except OSError:
-        pass
+        return None
+    if "x3" not in rows:
+        return None
+    return {"gbs": rows["x3"]["gbs"], "us_per_group": rows["x3"]["us_per_group"], "frames": want, "source": f"profiles/{name} (committed run, another box)"}
+
+
+def preflight_need_bytes(h, w, B, elem_bytes, persistence, out_slots, keep_states):
+    """Device memory one rank of the bench allocates: the B resident input frames, the engine's output slots, the float32 local states it
+    keeps per slot (+ chunk-final / zero / carry frames), the library's pre-warp scratch (<= 2 x 224 MB) and the 2 GiB of `copy_ceiling`."""
+    frame = h * w * 3
+    need = B * frame * elem_bytes                      # frames resident for the whole run
+    need += B * frame if elem_bytes > 1 else 0         # half frames are synthesised as uint8 and converted: both copies exist for a moment
+    need += 8 * frame * 16                             # synth_frames' per-frame int32 / float32 temporaries
+    need += out_slots * B * frame * elem_bytes
+    if persistence > 0.0:
+        need += (out_slots * (keep_states + 1) + 3) * frame * 4
+    need += 2 * (224 << 20) + (2 << 30)
+    return need
+
+
+def preflight(a, world, rank, local_rank, backend, h, w, B, elem_bytes, persistence, out_slots, keep_states):
+    """Checks made by every rank BEFORE the rendezvous and before anything large is allocated; returns a one-line reason or None.  A rank
+    that fails exits non-zero at once, and torch.distributed.run then tears the other ranks down: a mis-sized or mis-launched N-rank run ends
+    in seconds with a reason instead of hanging at the rendezvous or dying in an allocation halfway through the warm-up."""
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        return f"--gpus {world} over RCCL needs {world} visible devices, this rank sees {ndev} (CRTFX_DIST_BACKEND=gloo rehearses more ranks than GPUs)"
+    if backend == "nccl" and local_rank >= ndev:
+        return f"LOCAL_RANK {local_rank} has no device ({ndev} visible)"
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    free, total = torch.cuda.mem_get_info(dev_index)
+    sharing = 1 if backend == "nccl" else -(-world // max(1, ndev))       # gloo rehearsal: several ranks share one device
+    need = preflight_need_bytes(h, w, B, elem_bytes, persistence, out_slots, keep_states)
+    if need * sharing > free:
+        return (f"rank {rank}: {B} frames of {w}x{h} per step need {need / 2**30:.1f} GiB of device memory"
+                f"{' x ' + str(sharing) + ' ranks on this device' if sharing > 1 else ''}, {free / 2**30:.1f} of {total / 2**30:.1f} GiB are free — lower --batch")
     return None
 
 
@@ -210,6 +273,16 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def backend_version(backend):
+    """Version string of the collective library the ranks talk through (RCCL reports itself through torch's nccl binding)."""
+    try:
+        if backend == "nccl":
+            return "rccl " + ".".join(str(x) for x in torch.cuda.nccl.version())
+        return f"gloo (torch {torch.__version__})"
+    except Exception as e:      # noqa: BLE001 - a version string must never cost a bench line
+        return f"unknown ({e.__class__.__name__})"
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -277,13 +350,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl")      # "gloo": rehearsal of several ranks on fewer GPUs (never a result)
-    device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
     from pythoncrt_amd import effects
     from pythoncrt_amd.pipeline import FramePipeline, GpuShardEngine, baseline_config
@@ -294,6 +360,26 @@ def main():
     rs, h, w = baseline_config(a.config)
     fps = 30.0
     p = rs.persistence
+    # ---- pre-flight: device count and device memory, before the rendezvous (a failing rank exits at once with a one-line reason) ----
+    B_plan = a.batch or (384 if h >= 4320 else 1920 if h >= 2160 else 8192)
+    if p > 0.0 and not a.batch:
+        B_plan = max(settle_frames(p), 4096 if world > 1 else 8192)
+    why = preflight(a, world, rank, local_rank, backend, h, w, B_plan, 2 if a.config == 5 else 1, p, 2 if (p > 0.0 and world > 1) else 1,
+                    min(B_plan, settle_frames(p, 2.0 ** -26)) if p > 0.0 else 0)
+    if why:
+        print(f"bench.py preflight failed: {why}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never arrives (it failed its pre-flight, or was never started) must not leave the others at the rendezvous for the
+        # default half hour: one minute, then init_process_group raises and the job ends non-zero
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("CRTFX_RENDEZVOUS_TIMEOUT_S", "60"))),
+                                **({"device_id": device} if backend == "nccl" else {}))
     # frames per step: enough that the default 20 steps run >= 3 s — a timed region the driver's 5-s GPU-busy sampler
     # cannot miss (4K: 1920 frames = 47.8 GB in + 47.8 GB out of the 288 GB; 1080p: 8192 frames = 51 GB each way; 8K fp16:
     # 384 frames = 76.4 GB each way).  Sharded persistence needs B >= settle_frames(p) anyway (shard.py); per-frame states
@@ -344,6 +430,12 @@ def main():
         one_step(s)
     render.flush()
     sync()
+    # k_warp's yardstick, measured on this box between the warm-up and the timed region (rank 0; a child process, ~1 s)
+    mall_now = None
+    if rank == 0 and rs.warp_strength != 0.0 and not a.no_profile:
+        mall_now = mall_ceiling(pipe.plan().get("group_max", 1), h, w)
+    if dist is not None:
+        dist.barrier()
     prof = not a.no_profile
     region_dt = []
     kt = {}
@@ -420,7 +512,10 @@ def main():
         "host_tables": {"in_timed_region": not a.tables_outside, "host_seconds_rank0": round(host_first, 4),
                         "note": "per-frame scanline/flicker tables + frame records built and uploaded per step; they overlap the previous step's kernels"},
         "repeat_values": [round(total_frames / d, 2) for d in region_dt[1:]],
-        "dist": {"backend": backend if world > 1 else None, "world_size_seen": (dist.get_world_size() if dist is not None else 1),
+        "dist": {"backend": backend if world > 1 else None, "backend_version": backend_version(backend) if world > 1 else None,
+                 "world_size_seen": (dist.get_world_size() if dist is not None else 1), "visible_devices": torch.cuda.device_count(),
+                 # how the one-frame persistence hop ran (config 4 at N > 1 only): behind each round's scan ("synchronous") or beside the next one
+                 "hop_schedule": (("overlapped" if render.overlap else "synchronous") if (p > 0.0 and world > 1) else None),
                  "per_rank_frames_per_s": per_rank, "per_rank": per_rank_detail},
     }
     if p > 0.0 and world > 1:
@@ -525,10 +620,13 @@ def main():
                 "valu": valu, "lds": lds,
                 "copy_ceiling": copy_ceiling(device),
                 # ... and what reading one launch group's float32 pre-warp images back out of the Infinity Cache reaches (k_warp's yardstick)
-                "mall_ceiling": mall_ceiling(fpl, h) if rs.warp_strength != 0.0 else None,
+                "mall_ceiling": mall_now,
                 "kernels": {k: {"avg_launch_ms": round(v[0], 4), "timed_launches": v[1], "frames_per_launch": round(v[2] / v[1], 3)}
                             for k, v in kt.items()},
+                "plan": pipe.plan(),      # crtfx_last_plan: the kernel builds the timed launches landed on
             }
+            # figures NOT measured in this run (another box of the same chip model): context only, never part of `roofline`
+            res["reference_figures"] = {"mall_ceiling_committed": mall_ceiling_committed(fpl, h) if rs.warp_strength != 0.0 else None}
         if world == 1 and a.cpu_frames != 0 and a.config != 5:
             n_cpu = a.cpu_frames if a.cpu_frames > 0 else (8 if h >= 2160 else 32)   # ~10-12 s of CPU work (single thread + the 2-worker repeat)
             v, secs, v2 = cpu_baseline(rs, h, w, fps, n_cpu)

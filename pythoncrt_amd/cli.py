@@ -20,6 +20,15 @@ Host staging (the reference's reader / writer pipes ref:469-514
 input batches, a writer thread drains pinned output batches, and the GPU side runs on THREE streams — upload, kernels, download —
 chained by events, so that batch k+1's upload, batch k's kernels and batch k-1's download are in flight together (the two PCIe
 directions are independent DMA engines) while the host reads batch k+2 and writes batch k-2.
+
+Regular files skip the pinned staging where the platform lets them (`--io auto`, round 5): the input file is mapped MAP_SHARED and the
+windows of the mapping a batch covers are registered with the HIP runtime (hipHostRegister), so the upload DMA reads the page cache itself —
+no page-cache -> pinned memcpy; the output file is sized up front (ftruncate), mapped and registered the same way and the download DMA writes
+the page cache itself — no pinned -> page-cache copy.  Whether that wins depends on the filesystem (profiles/r05_hostreg_probe*.txt: on a
+disk-backed filesystem registering a fresh 398 MB batch takes 4.6 ms, on tmpfs — 4 KB pages, every one marked accessed on first touch —
+23-30 ms, slower than sixteen memcpy threads), so the first batch is timed and the staged path takes over when registration is refused or
+slower than `_MAPPED_MIN_GBS`.  Pipes get the largest pipe buffer the kernel allows (F_SETPIPE_SZ, 1 MiB) and are read / written straight
+from / to the pinned slots.
 """
 from __future__ import annotations
 
@@ -86,6 +95,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch", type=int, default=16, help="frames enqueued per GPU batch")
     p.add_argument("--staging-report", action="store_true", help="print where the reader / GPU-feeding / writer threads spent their time")
     p.add_argument("--noise-seed", type=int, default=None, help="seed of the counter-based grain RNG (default: random)")
+    p.add_argument("--io", type=str, default="staged", choices=["auto", "staged", "mapped"],
+                   help="regular files: through pinned staging slots (staged, the default: at the PCIe rate on a disk-backed filesystem), DMA "
+                        "straight from / into the registered file mapping (mapped: measured slower on this platform, profiles/r05_cli_throughput.txt), "
+                        "or mapped where the first batch shows it is faster (auto)")
     return p
 
 
@@ -151,7 +164,8 @@ def _io_pool():
             cpus = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             cpus = os.cpu_count() or 2
-        _IO_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(16, cpus // 2)), thread_name_prefix="crtfx-io")
+        want = int(os.environ.get("CRTFX_IO_THREADS", "0") or 0)          # A/B knob (tools/cli_throughput.sh); default: half the cpus, at most 16
+        _IO_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=want if want > 0 else max(1, min(16, cpus // 2)), thread_name_prefix="crtfx-io")
     return _IO_POOL
 
 
@@ -187,6 +201,7 @@ class _MappedInput:
     def __init__(self, fd: int):
         import mmap
         import os
+        self.fd, self._os = fd, os
         self.size = os.fstat(fd).st_size
         self.map = mmap.mmap(fd, self.size, prot=mmap.PROT_READ) if self.size > 0 else None
         self.arr = np.frombuffer(self.map, dtype=np.uint8) if self.map is not None else None
@@ -194,7 +209,13 @@ class _MappedInput:
 
     def read_into(self, dst: np.ndarray, offset: int) -> int:
         """Fill the uint8 array `dst` from the file at `offset`; returns the bytes copied (short only at end of file)."""
-        n = max(0, min(dst.size, self.size - offset))
+        # a file that was truncated under us ends the clip early (a short read, as read(2) would report it) instead of a SIGBUS from the
+        # pages that are gone: the size is looked at again before every batch
+        try:
+            now = self._os.fstat(self.fd).st_size
+        except OSError:
+            now = self.size
+        n = max(0, min(dst.size, min(self.size, now) - offset))
         if n <= 0:
             return 0
         ahead = min(self.size, offset + 3 * dst.size) - (offset + n)
@@ -208,6 +229,8 @@ class _MappedInput:
 
         page = self._mmap.PAGESIZE
         drop = getattr(self._mmap, "MADV_DONTNEED", None)
+        if self._os.environ.get("CRTFX_IO_DONTNEED", "1") == "0":       # A/B knob: leave the copied pages mapped until the process ends
+            drop = None
 
         def one(lo):
             hi = min(n, lo + _IO_SLICE)
@@ -264,23 +287,200 @@ def _seekable(f) -> bool:
         return False
 
 
-class _Reader:
-    """A thread that fills pinned (B, H, W, 3) uint8 slots ahead of the GPU: `jobs` yields (byte offset | None, frames) requests — an offset
-    for positional reads of a regular file, None for the next bytes of a stream — and `get()` hands back (slot index, pinned tensor,
-    frames actually read) in order, or None at the end.  `release(i)` returns a slot once its upload has completed."""
+def _grow_pipe(f, want: int = 0) -> int:
+    """F_SETPIPE_SZ on a pipe end (Linux): the default 64 KiB buffer makes a 24.9 MB 4K frame 380 wake-ups of the process on the other
+    side; 1 MiB is what an unprivileged process may ask for (/proc/sys/fs/pipe-max-size).  Returns the buffer size now in force (0: not a
+    pipe / not supported)."""
+    import fcntl
+    import os
+    import stat
+    try:
+        fd = f.fileno()
+        if not stat.S_ISFIFO(os.fstat(fd).st_mode):
+            return 0
+        if want <= 0:                              # CRTFX_PIPE_SIZE: A/B of the buffer size (tools/cli_throughput.sh); 0 bytes = leave the pipe as it is
+            want = int(os.environ.get("CRTFX_PIPE_SIZE", 1 << 20))
+        F_SETPIPE_SZ, F_GETPIPE_SZ = getattr(fcntl, "F_SETPIPE_SZ", 1031), getattr(fcntl, "F_GETPIPE_SZ", 1032)
+        try:
+            if want > 0:
+                fcntl.fcntl(fd, F_SETPIPE_SZ, want)
+        except OSError:
+            pass                                   # above pipe-max-size: keep what we have
+        return int(fcntl.fcntl(fd, F_GETPIPE_SZ))
+    except (OSError, ValueError, AttributeError):
+        return 0
 
-    def __init__(self, fin, positional: bool, jobs, shape, frame_bytes: int, slots: int = 3):
+
+class _HostDma:
+    """hipHostRegister / hipHostUnregister / hipMemcpyAsync of the HIP runtime this process has already loaded (torch's), through ctypes —
+    plain pointers and sizes.  What they are for: the PCIe DMA engines read a batch straight out of, or write it straight into, a shared
+    mapping of the raw rgb24 FILE (the page cache), with no pinned staging copy on the host."""
+    H2D, D2H = 1, 2
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes
+            path = None
+            try:
+                with open("/proc/self/maps") as maps:
+                    for line in maps:
+                        if "libamdhip64" in line:
+                            path = line.split()[-1]
+                            break
+            except OSError:
+                pass
+            lib = ctypes.CDLL(path or "libamdhip64.so")
+            lib.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+            lib.hipHostRegister.restype = ctypes.c_int
+            lib.hipHostUnregister.argtypes = [ctypes.c_void_p]
+            lib.hipHostUnregister.restype = ctypes.c_int
+            lib.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+            lib.hipMemcpyAsync.restype = ctypes.c_int
+            lib.hipGetLastError.restype = ctypes.c_int
+            cls._lib = lib
+        return cls._lib
+
+    @classmethod
+    def register(cls, ptr: int, n: int) -> bool:
+        lib = cls.lib()
+        if lib.hipHostRegister(ptr, n, 0) != 0:
+            lib.hipGetLastError()                  # clear the sticky error: the caller falls back to staging
+            return False
+        return True
+
+    @classmethod
+    def unregister(cls, ptr: int):
+        if cls.lib().hipHostUnregister(ptr) != 0:
+            cls.lib().hipGetLastError()
+
+    @classmethod
+    def copy(cls, dst: int, src: int, n: int, kind: int, stream: int):
+        rc = cls.lib().hipMemcpyAsync(dst, src, n, kind, stream)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpyAsync failed with error {rc}")
+
+
+_MAPPED_MIN_GBS = 30.0          # --io auto: registration slower than this per byte (tmpfs: 13-17 GB/s) loses to the memcpy staging
+
+
+class _RegisteredMap:
+    """A MAP_SHARED mapping of a regular file whose pages the GPU's DMA engines address directly.  Windows of WIN bytes (page multiples,
+    on a fixed grid so that the page two neighbouring batches share is never registered twice) are registered with the HIP runtime when a
+    batch first needs them and unregistered when the last batch using them is done."""
+    WIN = 32 << 20
+
+    def __init__(self, fd: int, size: int, writable: bool):
+        import mmap
+        import threading
+        self.size = int(size)
+        self.map = mmap.mmap(fd, self.size, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ | (mmap.PROT_WRITE if writable else 0))
+        self.arr = np.frombuffer(self.map, dtype=np.uint8)
+        self.base = int(self.arr.ctypes.data)
+        self.maplen = -(-self.size // mmap.PAGESIZE) * mmap.PAGESIZE
+        self.ref, self.lock = {}, threading.Lock()
+        self.t_reg = 0.0                        # seconds spent in hipHostRegister
+
+    def _span(self, w):
+        lo = w * self.WIN
+        return lo, min(self.WIN, self.maplen - lo)
+
+    def acquire(self, off: int, n: int) -> bool:
+        """Make the bytes [off, off + n) DMA-addressable; False when the runtime refuses (nothing stays registered for this call)."""
+        ws = range(off // self.WIN, (off + n - 1) // self.WIN + 1)
+        done = []
+        with self.lock:
+            for w in ws:
+                if self.ref.get(w, 0) == 0:
+                    lo, ln = self._span(w)
+                    t = time.perf_counter()
+                    ok = _HostDma.register(self.base + lo, ln)
+                    self.t_reg += time.perf_counter() - t
+                    if not ok:
+                        for v in done:
+                            self._drop(v)
+                        return False
+                self.ref[w] = self.ref.get(w, 0) + 1
+                done.append(w)
+        return True
+
+    def _drop(self, w):
+        c = self.ref.get(w, 0) - 1
+        if c <= 0:
+            self.ref.pop(w, None)
+            _HostDma.unregister(self.base + w * self.WIN)
+        else:
+            self.ref[w] = c
+
+    def release(self, off: int, n: int):
+        with self.lock:
+            for w in range(off // self.WIN, (off + n - 1) // self.WIN + 1):
+                self._drop(w)
+
+    def copy(self, kind: int, dev_ptr: int, off: int, n: int, stream: int):
+        """hipMemcpyAsync between device memory at dev_ptr and the file bytes [off, off + n), window by window: every window is a
+        registration of its own, and the runtime rejects a single copy that runs across two of them."""
+        pos = 0
+        while pos < n:
+            w = (off + pos) // self.WIN
+            k = min(n - pos, (w + 1) * self.WIN - (off + pos))
+            host = self.base + off + pos
+            if kind == _HostDma.H2D:
+                _HostDma.copy(dev_ptr + pos, host, k, kind, stream)
+            else:
+                _HostDma.copy(host, dev_ptr + pos, k, kind, stream)
+            pos += k
+
+    def close(self):
+        with self.lock:
+            for w in list(self.ref):
+                _HostDma.unregister(self.base + w * self.WIN)
+            self.ref.clear()
+        self.arr = None
+        try:
+            self.map.close()
+        except (BufferError, ValueError):
+            pass
+
+
+class _MapTok:
+    """One batch that lives in a registered file mapping: byte range + the flow-control slot it holds."""
+    __slots__ = ("off", "nbytes", "slot")
+
+    def __init__(self, off, nbytes, slot):
+        self.off, self.nbytes, self.slot = off, nbytes, slot
+
+
+class _Reader:
+    """A thread that gets input batches ready ahead of the GPU.  `jobs` yields (byte offset | None, frames) requests — an offset for
+    positional reads of a regular file, None for the next bytes of a stream — and `get()` hands back (token, frames, bytes) in order, or
+    None at the end; `upload(token, frames, dst, stream)` enqueues the batch's host-to-device copy and `release(token)` returns its slot
+    once that copy has completed.  Two ways a batch gets ready:
+      staged   filled into a pinned (B, H, W, 3) uint8 slot (token = slot index): read(2) / readinto for a stream, memcpy out of a
+               private mapping on the I/O threads for a regular file;
+      mapped   (io = "mapped" / "auto", regular files) the windows of a SHARED mapping of the file that the batch covers are registered
+               with the HIP runtime and the upload reads the page cache itself (token = _MapTok).  "auto" times the first batch and goes
+               back to staging when registration is refused or runs below _MAPPED_MIN_GBS."""
+
+    def __init__(self, fin, positional: bool, jobs, shape, frame_bytes: int, slots: int = 3, io: str = "staged"):
+        import os
         import queue
         import threading
         import torch
-        self.fin, self.positional, self.frame_bytes = fin, positional, frame_bytes
-        self.bufs = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.fin, self.positional, self.frame_bytes, self.shape = fin, positional, frame_bytes, shape
+        self._torch = torch
+        self._bufs = [None] * slots
         self.free, self.full = queue.Queue(), queue.Queue()      # the free-slot queue already bounds what is in flight
         for i in range(slots):
             self.free.put(i)
         self.err = None
         self.t_wait = self.t_io = 0.0          # seconds this thread waited for a free slot / spent reading (the --staging-report line)
-        self.mapped = None
+        self.mapped = None                     # private mapping the staged path copies out of
+        self.rmap = None                       # shared, registered mapping of the mapped path
+        self.mode = "staged"                   # what the NEXT batch will use
+        self.mapped_batches = self.staged_batches = 0
+        self.note = ""
         if positional:
             try:
                 self.mapped = _MappedInput(fin.fileno())
@@ -288,6 +488,47 @@ class _Reader:
                     self.mapped = None
             except (OSError, ValueError):
                 self.mapped = None             # not mappable: positional read(2) calls instead
+            if io in ("mapped", "auto") and self.mapped is not None:
+                try:
+                    self.rmap = _RegisteredMap(fin.fileno(), self.mapped.size, writable=False)
+                    self.mode = "mapped"
+                except (OSError, ValueError, AttributeError) as e:
+                    self.note = f"input mapping refused ({e.__class__.__name__}): staged"
+        if self.mode == "staged":
+            for i in range(slots):
+                self._buf(i)                   # pinned up front, as the GPU loop expects when it starts
+
+        def stage(i, off, nfr):
+            view = memoryview(self._buf(i).numpy()).cast("B")[: nfr * frame_bytes]
+            if self.mapped is not None:
+                got = self.mapped.read_into(self._buf(i).numpy().reshape(-1)[: nfr * frame_bytes], off)
+            else:
+                got = _pread_full(fin.fileno(), view, off) if positional else _read_into(fin, view)
+            self.staged_batches += 1
+            return i, got, len(view)
+
+        def map_batch(i, off, nfr):
+            """-> (token, got, wanted) or None when this batch has to be staged"""
+            try:
+                now = os.fstat(fin.fileno()).st_size
+            except OSError:
+                now = self.rmap.size
+            want = nfr * frame_bytes
+            got = max(0, min(want, min(self.rmap.size, now) - off))
+            nbytes = (got // frame_bytes) * frame_bytes
+            if nbytes:
+                t = time.perf_counter()
+                ok = self.rmap.acquire(off, nbytes)
+                dt = time.perf_counter() - t
+                if not ok:
+                    self.mode, self.note = "staged", "hipHostRegister refused the input mapping: staged"
+                    return None
+                if io == "auto" and self.mapped_batches == 0 and nbytes / max(dt, 1e-9) / 1e9 < _MAPPED_MIN_GBS:
+                    # this batch is registered and is used as it is; the ones behind it are staged
+                    self.mode = "staged"
+                    self.note = f"registering the input mapping ran at {nbytes / max(dt, 1e-9) / 1e9:.1f} GB/s (< {_MAPPED_MIN_GBS:.0f}): staged from the second batch on"
+            self.mapped_batches += 1
+            return _MapTok(off, nbytes, i), got, want
 
         def loop():
             try:
@@ -297,15 +538,14 @@ class _Reader:
                     self.t_wait += time.perf_counter() - t
                     if i is None:
                         return
-                    view = memoryview(self.bufs[i].numpy()).cast("B")[: nfr * frame_bytes]
                     t = time.perf_counter()
-                    if self.mapped is not None:
-                        got = self.mapped.read_into(self.bufs[i].numpy().reshape(-1)[: nfr * frame_bytes], off)
-                    else:
-                        got = _pread_full(fin.fileno(), view, off) if positional else _read_into(fin, view)
+                    res = map_batch(i, off, nfr) if self.mode == "mapped" else None
+                    if res is None:
+                        res = stage(i, off, nfr)
+                    tok, got, want = res
                     self.t_io += time.perf_counter() - t
-                    self.full.put((i, got // frame_bytes, got))
-                    if got < len(view):
+                    self.full.put((tok, got // frame_bytes, got))
+                    if got < want:
                         break
             except BaseException as e:      # noqa: BLE001 - re-raised on the consumer's side
                 self.err = e
@@ -313,72 +553,177 @@ class _Reader:
         self.thr = threading.Thread(target=loop, name="crtfx-reader", daemon=True)
         self.thr.start()
 
+    def _buf(self, i):
+        if self._bufs[i] is None:
+            self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
+        return self._bufs[i]
+
+    @property
+    def bufs(self):
+        return [self._buf(i) for i in range(len(self._bufs))]
+
     def get(self):
         item = self.full.get()
         if self.err is not None:
             raise self.err
         return item
 
-    def release(self, i: int):
-        self.free.put(i)
+    def upload(self, tok, n: int, dst, stream):
+        """Enqueue the host-to-device copy of the batch's first n frames into dst[:n] on `stream` (a torch stream)."""
+        if isinstance(tok, _MapTok):
+            self.rmap.copy(_HostDma.H2D, dst.data_ptr(), tok.off, n * self.frame_bytes, stream.cuda_stream)
+        else:
+            with self._torch.cuda.stream(stream):
+                dst[:n].copy_(self._buf(tok)[:n], non_blocking=True)
+
+    def release(self, tok):
+        if isinstance(tok, _MapTok):
+            if tok.nbytes:
+                self.rmap.release(tok.off, tok.nbytes)
+            self.free.put(tok.slot)
+        else:
+            self.free.put(tok)
 
     def close(self):
         self.free.put(None)
         self.thr.join(timeout=30)
+        if self.rmap is not None:
+            self.rmap.close()
         if self.mapped is not None:
             self.mapped.close()
 
 
 class _Writer:
-    """A thread that waits for a download's event and writes the pinned batch out (positional for a regular file), then hands the slot
-    back.  `slot()` blocks until a pinned output slot is free; `put(i, frames, event, offset)` queues it."""
+    """A thread that finishes output batches behind the GPU.  `slot()` blocks until a destination is free and returns its token;
+    `download(token, frames, src, stream)` enqueues the device-to-host copy; `put(token, frames, event, offset)` queues the batch for the
+    thread, which waits for the event and
+      staged   writes the pinned slot out (token = slot index; positional pwrite slices for a regular file, write() for a stream);
+      mapped   (regular output file whose final size is known: `plan` = [(offset, bytes), ...]) has nothing left to write — the file was
+               sized with ftruncate, mapped MAP_SHARED, and a helper thread registered each batch's windows with the HIP runtime ahead of
+               the GPU, so the download DMA wrote the page cache itself; the thread only unregisters the windows.
+    After the first write error nothing more is written: the remaining jobs are drained (their slots go back) and the first error is kept."""
 
-    def __init__(self, fout, positional: bool, shape, frame_bytes: int, slots: int = 3):
+    def __init__(self, fout, positional: bool, shape, frame_bytes: int, slots: int = 3, plan=None, io: str = "staged"):
+        import os
         import queue
         import threading
         import torch
-        self.bufs = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self._torch, self.shape, self.frame_bytes = torch, shape, frame_bytes
+        self._bufs = [None] * slots
         self.free, self.work = queue.Queue(), queue.Queue()
         for i in range(slots):
             self.free.put(i)
         self.err, self.frames = None, 0
         self.t_wait = self.t_io = 0.0          # seconds this thread waited for downloads / spent writing
+        self.rmap, self.ready, self.prep = None, None, None
+        self.note = ""
+        self.mapped_batches = 0
+        self.t_prep = 0.0
+        if positional and plan and io in ("mapped", "auto"):
+            total = plan[-1][0] + plan[-1][1]
+            try:
+                os.ftruncate(fout.fileno(), total)
+                self.rmap = _RegisteredMap(fout.fileno(), total, writable=True)
+            except (OSError, ValueError, AttributeError) as e:
+                self.rmap, self.note = None, f"output mapping refused ({e.__class__.__name__}): staged"
+        if self.rmap is not None:
+            self.ready = queue.Queue()
+            self.tokens = threading.Semaphore(slots)      # batches registered ahead of / in flight on the GPU
+
+            def prepare():
+                for off, nbytes in plan:
+                    self.tokens.acquire()
+                    if self.stop_prep:
+                        return
+                    t = time.perf_counter()
+                    ok = self.rmap.acquire(off, nbytes)
+                    self.t_prep += time.perf_counter() - t
+                    if not ok:
+                        self.note = "hipHostRegister refused the output mapping: staged"
+                        self.ready.put(None)           # from here on: pinned slots + pwrite into the (already sized) file
+                        return
+                    self.ready.put(_MapTok(off, nbytes, None))
+                self.ready.put(None)
+            self.stop_prep = False
+            self.prep = threading.Thread(target=prepare, name="crtfx-out-prep", daemon=True)
+            self.prep.start()
+        else:
+            for i in range(slots):
+                self._buf(i)
 
         def loop():
             while True:
                 job = self.work.get()
                 if job is None:
                     return
-                i, n, ev, off = job
+                tok, n, ev, off = job
                 try:
                     t = time.perf_counter()
                     ev.synchronize()
                     self.t_wait += time.perf_counter() - t
-                    view = memoryview(self.bufs[i].numpy()).cast("B")[: n * frame_bytes]
-                    t = time.perf_counter()
-                    if positional:
-                        _pwrite_full(fout.fileno(), view, off)
-                    else:
-                        fout.write(view)
-                    self.t_io += time.perf_counter() - t
-                    self.frames += n
+                    if isinstance(tok, _MapTok):
+                        self.frames += n
+                    elif self.err is None:          # after a write error: no further writes, the slots still go back
+                        view = memoryview(self._buf(tok).numpy()).cast("B")[: n * frame_bytes]
+                        t = time.perf_counter()
+                        if positional:
+                            _pwrite_full(fout.fileno(), view, off)
+                        else:
+                            fout.write(view)
+                        self.t_io += time.perf_counter() - t
+                        self.frames += n
                 except BaseException as e:      # noqa: BLE001
-                    self.err = e
-                self.free.put(i)
+                    if self.err is None:
+                        self.err = e
+                if isinstance(tok, _MapTok):
+                    self.rmap.release(tok.off, tok.nbytes)
+                    self.tokens.release()
+                else:
+                    self.free.put(tok)
         self.thr = threading.Thread(target=loop, name="crtfx-writer", daemon=True)
         self.thr.start()
 
-    def slot(self) -> int:
+    def _buf(self, i):
+        if self._bufs[i] is None:
+            self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
+        return self._bufs[i]
+
+    @property
+    def bufs(self):
+        return [self._buf(i) for i in range(len(self._bufs))]
+
+    def slot(self):
         if self.err is not None:
             raise self.err
+        if self.ready is not None:
+            tok = self.ready.get()
+            if tok is not None:
+                self.mapped_batches += 1
+                return tok
+            self.ready = None                      # the plan is used up (a longer input than planned cannot happen) or registration failed
         return self.free.get()
 
-    def put(self, i: int, n: int, ev, off):
-        self.work.put((i, n, ev, off))
+    def download(self, tok, n: int, src, stream):
+        """Enqueue the device-to-host copy of src[:n] into the batch's destination on `stream` (a torch stream)."""
+        if isinstance(tok, _MapTok):
+            self.rmap.copy(_HostDma.D2H, src.data_ptr(), tok.off, n * self.frame_bytes, stream.cuda_stream)
+        else:
+            with self._torch.cuda.stream(stream):
+                self._buf(tok)[:n].copy_(src[:n], non_blocking=True)
+
+    def put(self, tok, n: int, ev, off):
+        self.work.put((tok, n, ev, off))
 
     def close(self):
         self.work.put(None)
         self.thr.join()
+        if self.prep is not None:
+            self.stop_prep = True
+            for _ in range(len(self._bufs) + 1):
+                self.tokens.release()
+            self.prep.join(timeout=30)
+        if self.rmap is not None:
+            self.rmap.close()
         if self.err is not None:
             raise self.err
 
@@ -533,13 +878,25 @@ def main(argv=None) -> int:
     pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=seed, text_overlay_rgba=overlay, text_overlay_after=bool(a.text_after))
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb", buffering=0)
     out_path = a.output if a.output else (a.input + "_crt.rgb" if a.input != "-" else "-")
-    fout = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
     B = max(1, int(a.batch))
     frame_bytes = h * w * 3
     t0 = time.perf_counter()
     # regular files: positional I/O on a few threads (a pipe / the terminal: the plain sequential calls)
     in_pos = _seekable(fin) and a.input != "-"
+    # the output is opened with read access too (a MAP_SHARED, PROT_WRITE mapping needs O_RDWR).  An existing regular output file behind a
+    # regular input file is NOT truncated at open: it is sized to the clip below, and the pages it already has in the page cache are
+    # overwritten in place (registering them is several times faster than allocating new ones)
+    keep_pages = in_pos and out_path != "-" and os.path.isfile(out_path) and not os.path.samefile(out_path, a.input)
+    fout = sys.stdout.buffer if out_path == "-" else open(out_path, "r+b" if keep_pages else "w+b")
     out_pos = fout is not sys.stdout.buffer and _seekable(fout)
+    pipe_in, pipe_out = (0 if in_pos else _grow_pipe(fin)), (0 if out_pos else _grow_pipe(fout))      # pipes: the largest buffer the kernel allows
+    # a regular input file fixes the clip's length, and with it the output file's size: the output can then be sized, mapped and registered
+    # up front (the zero-copy download); a stream's length is unknown, its output goes through the pinned slots
+    out_plan = None
+    if in_pos and out_pos:
+        n_total = os.fstat(fin.fileno()).st_size // frame_bytes
+        out_plan = [(k * B * frame_bytes, min(B, n_total - k * B) * frame_bytes) for k in range((n_total + B - 1) // B)] or None
+        os.ftruncate(fout.fileno(), n_total * frame_bytes)
 
     def jobs():                                                     # whole batches until the stream ends (the reader stops at a short read)
         off = 0
@@ -547,8 +904,8 @@ def main(argv=None) -> int:
             yield (off if in_pos else None), B
             off += B * frame_bytes
     NS = 3
-    reader = _Reader(fin, in_pos, jobs(), (B, h, w, 3), frame_bytes, slots=NS)
-    writer = _Writer(fout, out_pos, (B, h, w, 3), frame_bytes, slots=NS)
+    reader = _Reader(fin, in_pos, jobs(), (B, h, w, 3), frame_bytes, slots=NS, io=a.io)
+    writer = _Writer(fout, out_pos, (B, h, w, 3), frame_bytes, slots=NS, plan=out_plan, io=a.io)
     dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
     dev_out = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
     compute = torch.cuda.current_stream(dev)
@@ -572,12 +929,11 @@ def main(argv=None) -> int:
             if kernels_done[d] is not None:
                 s_up.wait_event(kernels_done[d])
             tim = a.staging_report
-            with torch.cuda.stream(s_up):
-                if tim:
-                    u0 = torch.cuda.Event(enable_timing=True); u0.record(s_up)
-                dev_in[d][:n].copy_(reader.bufs[i][:n], non_blocking=True)
-                up = torch.cuda.Event(enable_timing=tim)
-                up.record(s_up)
+            if tim:
+                u0 = torch.cuda.Event(enable_timing=True); u0.record(s_up)
+            reader.upload(i, n, dev_in[d], s_up)              # from the pinned slot, or straight from the registered file mapping
+            up = torch.cuda.Event(enable_timing=tim)
+            up.record(s_up)
             # kernels k behind the upload, and behind the download that last read this output slot
             compute.wait_event(up)
             if down_done[d] is not None:
@@ -595,12 +951,11 @@ def main(argv=None) -> int:
             t_slot += time.perf_counter() - tt
             tt = time.perf_counter()
             s_down.wait_event(kd)
-            with torch.cuda.stream(s_down):
-                if tim:
-                    d0 = torch.cuda.Event(enable_timing=True); d0.record(s_down)
-                writer.bufs[j][:n].copy_(dev_out[d][:n], non_blocking=True)
-                dn = torch.cuda.Event(enable_timing=tim)
-                dn.record(s_down)
+            if tim:
+                d0 = torch.cuda.Event(enable_timing=True); d0.record(s_down)
+            writer.download(j, n, dev_out[d], s_down)         # into the pinned slot, or straight into the registered output mapping
+            dn = torch.cuda.Event(enable_timing=tim)
+            dn.record(s_down)
             down_done[d] = dn
             if tim:
                 marks.append((u0, up, k0, kd, d0, dn, n))
@@ -629,6 +984,8 @@ def main(argv=None) -> int:
     writer.close()
     reader.close()
     fout.flush()
+    if out_pos:
+        os.ftruncate(fout.fileno(), index * frame_bytes)      # an input that ended before its planned length, an output file that was longer
     if fout is not sys.stdout.buffer:
         fout.close()
     if fin is not sys.stdin.buffer:
@@ -645,6 +1002,9 @@ def main(argv=None) -> int:
         print(f"staging (GPU side, per batch of {nb / frame_bytes:.0f} frames): upload {up_ms:.2f} ms = {nb / up_ms / 1e6:.1f} GB/s, kernels {k_ms:.2f} ms, "
               f"download {dn_ms:.2f} ms = {nb / dn_ms / 1e6:.1f} GB/s; one batch every {span:.2f} ms = {nb / frame_bytes / span * 1e3:.0f} frames/s", file=sys.stderr)
     if a.staging_report:
+        print(f"staging: input {reader.mapped_batches} batches mapped (hipHostRegister {reader.rmap.t_reg if reader.rmap else 0.0:.3f}s), {reader.staged_batches} staged"
+              f"{' — ' + reader.note if reader.note else ''} | output {writer.mapped_batches} batches mapped (register + page allocation {writer.t_prep:.3f}s)"
+              f"{' — ' + writer.note if writer.note else ''} | pipe buffers in {pipe_in} out {pipe_out} bytes", file=sys.stderr)
         print(f"staging: reader read {reader.t_io:.3f}s waited-for-slot {reader.t_wait:.3f}s | feeder waited-for-input {t_get:.3f}s enqueued {t_enq:.3f}s "
               f"waited-for-output-slot {t_slot:.3f}s waited-for-upload {t_rel:.3f}s | writer waited-for-download {writer.t_wait:.3f}s wrote {writer.t_io:.3f}s",
               file=sys.stderr)

@@ -33,7 +33,7 @@ def test_flag_names_and_defaults():
     for k, v in ref.items():
         assert k in ours, k
         assert ours[k] == v, (k, ours[k], v)
-    assert set(ours) - set(ref) == {"batch", "noise_seed", "staging_report"}      # the additions documented in cli.py
+    assert set(ours) - set(ref) == {"batch", "noise_seed", "staging_report", "io"}      # the additions documented in cli.py
 
 
 def test_clamps_match_reference_main():
@@ -108,3 +108,17 @@ def test_mapped_input_reads_like_the_file(tmp_path):
     assert m.map is None and m.read_into(small, 0) == 0
     m.close()
     os.close(fd)
+
+
+def test_cli_pipes_get_the_large_buffer():
+    """cli._grow_pipe: F_SETPIPE_SZ on both ends of a pipe (1 MiB, or the most the kernel grants); 0 for a regular file."""
+    from pythoncrt_amd import cli
+    r, wfd = os.pipe()
+    try:
+        with os.fdopen(r, "rb", buffering=0) as fr, os.fdopen(wfd, "wb", buffering=0) as fw:
+            got = cli._grow_pipe(fw)
+            assert got >= 65536 and cli._grow_pipe(fr) == got          # one buffer, seen from both ends
+        with open(__file__, "rb") as f:
+            assert cli._grow_pipe(f) == 0
+    finally:
+        pass

@@ -129,6 +129,47 @@ def test_overlay_of_another_size_matches_reference(pc):
         assert got.shape == exp.shape and np.array_equal(got, exp.astype(np.float32))
 
 
+@pytest.mark.parametrize("where", ["tmp", "shm"])
+def test_cli_io_modes_write_the_same_bytes(pc, tmp_path, where, capsys):
+    """--io staged (pinned slots + memcpy / pwrite), mapped (upload and download DMA straight from / into the registered file mappings) and auto
+    (mapped where the first batch shows it pays): identical output files.  Frames of 27 648 bytes in batches of 3 — no batch boundary on a
+    page, so neighbouring batches share a registered window — a short last batch, a clip shorter than one batch, a trailing partial frame,
+    persistence carried across batches; on the test's own directory and (when the box has one) on tmpfs, where registration is the slow
+    path and `auto` goes back to staging after the first batch."""
+    import shutil
+    import tempfile
+    from pythoncrt_amd import cli
+    base = tmp_path
+    if where == "shm":
+        if not os.path.isdir("/dev/shm") or not os.access("/dev/shm", os.W_OK):
+            pytest.skip("no writable /dev/shm")
+        base = type(tmp_path)(tempfile.mkdtemp(prefix="crtfx_io_", dir="/dev/shm"))
+    try:
+        for n, batch, (h, w) in ((11, 3, (72, 128)), (2, 5, (72, 128)), (6, 3, (72, 128)), (5, 2, (1080, 1920 * 4))):      # the last: 49.8 MB batches, several 32 MiB windows each
+            frames = clip(n, h, w, 31 + n)
+            src = base / "in.rgb"
+            src.write_bytes(frames.tobytes() + b"\x01\x02")
+            outs = {}
+            for io in ("staged", "mapped", "auto"):
+                dst = base / f"out_{io}.rgb"
+                rc = cli.main(["--input", str(src), "--output", str(dst), "--width", str(w), "--height", str(h), "--fps", "30", "--batch", str(batch),
+                               "--noise-seed", "5", "--warp-strength", "0.15", "--persistence", "0.4", "--io", io, "--staging-report"])
+                assert rc == 0
+                outs[io] = dst.read_bytes()
+                err = capsys.readouterr().err
+                line = [ln for ln in err.splitlines() if ln.startswith("staging: input")][0]
+                if io == "staged":
+                    assert "input 0 batches mapped" in line and "output 0 batches mapped" in line, line
+                elif io == "mapped" and "refused" not in line:
+                    # (the reader always asks for one batch more than the clip's whole batches: the short — possibly empty — one that ends it)
+                    assert f"input {n // batch + 1} batches mapped" in line and f"output {-(-n // batch)} batches mapped" in line, line
+            assert len(outs["staged"]) == frames.size
+            assert outs["mapped"] == outs["staged"] and outs["auto"] == outs["staged"], (n, batch)
+    finally:
+        if where == "shm":
+            shutil.rmtree(str(base), ignore_errors=True)
+
+
 @pytest.mark.parametrize("persistence,n_frames", [("0.5", 11), ("0", 9)])
 def test_sharded_cli_two_ranks(pc, tmp_path, persistence, n_frames):
     """SURVEY 8e end to end: two ranks (one process each, launched by torch.distributed.run; both on this box's single
@@ -258,7 +299,36 @@ def test_bench_launches_its_own_ranks(config, batch):
     assert [d["rank"] for d in pr] == [0, 1]
     for d in pr:
         assert d["frames_per_s_own_clock"] > 0 and d["chain_ms_per_frame"] > 0 and set(d["gpu"]) >= {"samples", "sclk_mhz_mean", "power_w_mean"}
+    assert res["dist"]["backend"] == "gloo" and res["dist"]["backend_version"].startswith("gloo") and res["dist"]["visible_devices"] >= 1
+    assert res["dist"]["hop_schedule"] == ("overlapped" if config == 4 else None)
     if config == 4:
         sr = res["shard_schedule"]
         assert sr["overlap"] and sr["parallel_hop"] and sr["rounds"] >= 2 and sr["fixup_frames"] == 26
         assert all(d["shard_schedule"]["rounds"] == sr["rounds"] for d in pr)      # the schedule of EVERY rank, not rank 0's only
+
+
+@pytest.mark.parametrize("case", ["too_many_frames", "more_ranks_than_gpus"])
+def test_bench_preflight_fails_fast_with_a_reason(case):
+    """An N-rank bench run that cannot work ends in seconds, non-zero, with ONE line saying why — before the rendezvous, before any large
+    allocation: (a) a batch that does not fit the device memory; (b) --gpus 2 over RCCL on a box with fewer devices (when this box has fewer
+    than 2).  (The rendezvous itself carries a 60 s timeout for a rank that never arrives.)"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    if case == "too_many_frames":
+        env["CRTFX_DIST_BACKEND"] = "gloo"
+        extra, want = ["--batch", "400000"], "lower --batch"
+    else:
+        if torch.cuda.device_count() >= 2:
+            pytest.skip("this box has two devices: the launch is valid")
+        env.pop("CRTFX_DIST_BACKEND", None)
+        extra, want = ["--batch", "8"], "visible devices"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "3", "--cpu-frames", "0", "--repeats", "0"] + extra
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 60, (r.returncode, took, r.stderr[-1500:])
+    assert "bench.py preflight failed" in r.stderr and want in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no result line

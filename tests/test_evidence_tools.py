@@ -63,19 +63,40 @@ def test_source_hash_covers_every_kernel_source():
 
 
 def test_bench_ceiling_and_telemetry_degrade_gracefully():
-    """bench.py's round-4 additions on a box without a GPU: the Infinity-Cache-resident ceiling comes from the committed microbenchmark
-    runs (4K groups, 1080p groups; nothing for other sizes), and the per-rank GPU telemetry turns into nulls with a note instead of raising
+    """bench.py's round-4 additions on a box without a GPU: the committed Infinity-Cache-resident ceiling of another box is a reference figure
+    (4K groups, 1080p groups; nothing for other sizes), the one in `roofline` is measured in the run or absent, and the per-rank GPU telemetry turns into nulls with a note instead of raising
     when rocm_smi / the device is unavailable."""
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    a = bench.mall_ceiling(2.0)
+    a = bench.mall_ceiling_committed(2.0, 2160)
     assert a and a["frames"] == 2 and 6000 < a["gbs"] < 8000 and a["source"].startswith("profiles/r04_mall_copy.txt")
-    b = bench.mall_ceiling(5.0, 1080)
+    b = bench.mall_ceiling_committed(5.0, 1080)
     assert b and b["frames"] == 5 and b["us_per_group"] > 0 and "1080p" in b["source"]
-    assert bench.mall_ceiling(1.0, 4320) is None and bench.mall_ceiling(7.0, 2160) is None
+    assert bench.mall_ceiling_committed(1.0, 4320) is None and bench.mall_ceiling_committed(7.0, 2160) is None
+    # the figure under `roofline` is measured in the run (tools/ubench/mall_copy.hip as a child process): without the program (or without a
+    # GPU: it then exits non-zero) there is NO figure, never the committed one of another box
+    rows = bench._mall_rows("2 frame(s) (199 MB float32 just written) x3          36.5 us    6814 GB/s (source + uint8 out)\n"
+                            "2 frame(s) (199 MB float32 just written) tap4        40.8 us    6095 GB/s (source + uint8 out)\n", 2)
+    assert rows["x3"] == {"us_per_group": 36.5, "gbs": 6814.0} and rows["tap4"]["us_per_group"] == 40.8
+    assert bench.mall_ceiling(2.0, 2160, 3840) is None
     import torch
     t = bench.GpuTelemetry(torch.device("cpu"))
     t.start()
     out = t.stop()
     assert out["sclk_mhz_mean"] is None and out["power_w_mean"] is None and out["samples"] == 0
+
+
+def test_bench_preflight_memory_estimate():
+    """bench.preflight_need_bytes: the default workloads fit one 288 GB MI355X with room to spare, an oversized batch does not, and the
+    estimate covers at least the buffers bench.py visibly allocates (resident frames + output slots)."""
+    import bench
+    gib = 2 ** 30
+    cases = {"4K": (2160, 3840, 1920, 1, 0.0, 1, 0), "1080p persistence sharded": (1080, 1920, 4096, 1, 0.5, 2, 26), "8K half": (4320, 7680, 384, 2, 0.0, 1, 0)}
+    for name, c in cases.items():
+        need = bench.preflight_need_bytes(*c)
+        h, w, b, eb, p, slots, keep = c
+        assert need >= b * h * w * 3 * eb * (1 + slots), name
+        assert need < 230 * gib, (name, need / gib)
+    assert bench.preflight_need_bytes(2160, 3840, 400000, 1, 0.0, 1, 0) > 288 * gib
+    assert bench.preflight_need_bytes(1080, 1920, 64, 1, 0.5, 2, 26) > bench.preflight_need_bytes(1080, 1920, 64, 1, 0.0, 2, 0)
