@@ -191,6 +191,22 @@ def _pread_full(fd: int, view: memoryview, offset: int) -> int:
     return total
 
 
+_LIBC = None
+
+
+def _madvise(addr: int, length: int, advice: int) -> int:
+    """madvise(2) through ctypes: the call runs WITHOUT the GIL.  mmap.madvise of CPython 3.10 keeps it, and dropping the page-table entries
+    of an 8 MiB slice takes ~0.3 ms: issued from sixteen copy threads that way, the drops ran one after the other and held up every other
+    Python thread of the process — the 4K reader delivered 19 GB/s instead of 50 (profiles/r05_cli_throughput.txt)."""
+    global _LIBC
+    if _LIBC is None:
+        import ctypes
+        _LIBC = ctypes.CDLL(None, use_errno=True)
+        _LIBC.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _LIBC.madvise.restype = ctypes.c_int
+    return _LIBC.madvise(addr, length, advice)
+
+
 class _MappedInput:
     """A regular input file mapped read-only: a batch is copied out of the page cache by user-space memcpy on the I/O threads
     (numpy's copy loop releases the GIL) instead of read(2).  Measured on the GPU box, 1.6 GB from tmpfs into a pinned buffer, eight
@@ -205,7 +221,31 @@ class _MappedInput:
         self.size = os.fstat(fd).st_size
         self.map = mmap.mmap(fd, self.size, prot=mmap.PROT_READ) if self.size > 0 else None
         self.arr = np.frombuffer(self.map, dtype=np.uint8) if self.map is not None else None
+        self.base = int(self.arr.ctypes.data) if self.arr is not None else 0
         self._mmap = mmap
+        # the page-table entries of what has been copied are dropped (the pages stay in the page cache) by ONE thread of its own, batch by
+        # batch behind the copies: unmapping costs ~0.15 us per 4 KB page wherever it is paid — in one piece at exit 0.9 s for a 24 GB clip;
+        # from the sixteen copy threads, slice by slice, the drops contend in the kernel (tmpfs: 28 ms per 400 MB batch when they really run in
+        # parallel, 17 ms serialised by the GIL as in round 4) and sit on the reader's critical path; one thread beside the copies does
+        # a batch in ~13 ms and delays nobody (profiles/r05_cli_throughput.txt)
+        import queue
+        import threading
+        self._zap_q = queue.Queue()
+        self._zap_mode = os.environ.get("CRTFX_IO_DONTNEED", "thread")      # A/B knob: "thread" (default) | "0" (never: left to process exit) | "slice" (on the copy threads, round 4)
+        self._zap_thr = None
+        if self.map is not None and self._zap_mode == "thread" and hasattr(mmap, "MADV_DONTNEED"):
+            def zapper():
+                while True:
+                    job = self._zap_q.get()
+                    if job is None:
+                        return
+                    a0, a1 = job
+                    while a0 < a1:
+                        k = min(a1 - a0, 32 << 20)
+                        _madvise(self.base + a0, k, mmap.MADV_DONTNEED)
+                        a0 += k
+            self._zap_thr = threading.Thread(target=zapper, name="crtfx-zap", daemon=True)
+            self._zap_thr.start()
 
     def read_into(self, dst: np.ndarray, offset: int) -> int:
         """Fill the uint8 array `dst` from the file at `offset`; returns the bytes copied (short only at end of file)."""
@@ -222,15 +262,10 @@ class _MappedInput:
         if ahead > 0 and hasattr(self._mmap, "MADV_WILLNEED"):
             page = self._mmap.PAGESIZE
             lo = ((offset + n) // page) * page
-            try:
-                self.map.madvise(self._mmap.MADV_WILLNEED, lo, min(self.size - lo, ahead + page))
-            except (OSError, ValueError):
-                pass
+            _madvise(self.base + lo, min(self.size - lo, ahead + page), self._mmap.MADV_WILLNEED)
 
         page = self._mmap.PAGESIZE
-        drop = getattr(self._mmap, "MADV_DONTNEED", None)
-        if self._os.environ.get("CRTFX_IO_DONTNEED", "1") == "0":       # A/B knob: leave the copied pages mapped until the process ends
-            drop = None
+        drop = getattr(self._mmap, "MADV_DONTNEED", None) if self._zap_mode == "slice" else None
 
         def one(lo):
             hi = min(n, lo + _IO_SLICE)
@@ -242,16 +277,24 @@ class _MappedInput:
                 a0, a1 = ((offset + lo + page - 1) // page) * page, ((offset + hi) // page) * page
                 if a1 > a0:
                     try:
-                        self.map.madvise(drop, a0, a1 - a0)
+                        self.map.madvise(drop, a0, a1 - a0)      # mmap.madvise keeps the GIL: the drops of the sixteen threads run one after the other (on purpose, see __init__)
                     except (OSError, ValueError):
                         pass
         if n > _IO_SLICE:
             list(_io_pool().map(one, range(0, n, _IO_SLICE)))
         else:
             one(0)
+        if self._zap_thr is not None:
+            a0, a1 = ((offset + page - 1) // page) * page, ((offset + n) // page) * page
+            if a1 > a0:
+                self._zap_q.put((a0, a1))
         return n
 
     def close(self):
+        if self._zap_thr is not None:
+            self._zap_q.put(None)
+            self._zap_thr.join(timeout=30)
+            self._zap_thr = None
         self.arr = None
         if self.map is not None:
             try:

@@ -57,6 +57,7 @@ PY
 for io in staged mapped auto; do case_ "file -> /dev/null, --io $io" file /dev/null $io; done
 if [ -n "$KNOBS" ]; then      # A/B of the staged reader's knobs (KNOBS=1)
   CRTFX_IO_DONTNEED=0 case_ "file -> /dev/null, staged, no MADV_DONTNEED behind the copies" file /dev/null staged
+  CRTFX_IO_DONTNEED=slice case_ "file -> /dev/null, staged, MADV_DONTNEED per slice on the copy threads (round 4)" file /dev/null staged
   CRTFX_IO_THREADS=32 case_ "file -> /dev/null, staged, 32 I/O threads" file /dev/null staged
   CRTFX_IO_THREADS=8 case_ "file -> /dev/null, staged, 8 I/O threads" file /dev/null staged
   BATCH=32 case_ "file -> /dev/null, staged, batches of 32 frames" file /dev/null staged
