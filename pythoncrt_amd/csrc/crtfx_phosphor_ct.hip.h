@@ -67,7 +67,9 @@ __host__ __device__ constexpr int ct_lds_words(int R, int pix = 0) {
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 15 ? CT_WAVES : (R <= 20 ? 3 : 2); }
 #ifndef CT_HALF_MAX_RADIUS
-#define CT_HALF_MAX_RADIUS 12      // the half build's radii (crtfx_rr.hip, launch_rr_group): the centre window takes (R + 9) / 2 VGPRs more than the uint8 build
+#define CT_HALF_MAX_RADIUS 15      // the half build's radii (crtfx_rr.hip, launch_rr_group).  Its centre window takes (R + 9) / 2 VGPRs more than the uint8 build: no spills up to
+                                   // radius 12 (126 VGPRs), 15 - 22 spilled at four blocks from 13 — still ahead of or level with k_phosphor_rr<half> at three
+                                   // (4K half frames, us per frame: R 13 126 against 131 - 154, R 14 140 / 139 - 159, R 15 139 - 155 / 144 - 156; profiles/r05_half_sigma.txt)
 #endif
 
 template <int RT, int PIX = 0>
