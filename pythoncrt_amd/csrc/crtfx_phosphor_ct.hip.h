@@ -66,6 +66,8 @@ __host__ __device__ constexpr int ct_lds_words(int R, int pix = 0) {
     return NB * 3 * cc_sws(R) + NB * CC_HROW + 2 * LUT_STRIDE + ct_ring_words(R, pix) + NB * TW * 2 + 2 * NB * TW;
 }
 __host__ __device__ constexpr int ct_min_waves(int R) { return R <= 15 ? CT_WAVES : (R <= 20 ? 3 : 2); }
+#define CT_HALF_C_HI 0x1.0101p-8f          // float(h) / 255 as fma(f, C_HI, f * C_LO): 1/255 rounded down to float32 ...
+#define CT_HALF_C_LO 0x1.010102p-32f       // ... and float32(1/255 - C_HI) > 0
 #ifndef CT_HALF_MAX_RADIUS
 #define CT_HALF_MAX_RADIUS 15      // the half build's radii (crtfx_rr.hip, launch_rr_group).  Its centre window takes (R + 9) / 2 VGPRs more than the uint8 build: no spills up to
                                    // radius 12 (126 VGPRs), 15 - 22 spilled at four blocks from 13 — still ahead of or level with k_phosphor_rr<half> at three
@@ -176,10 +178,16 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
     // correctly rounded quotient for every byte (the sum carries f / 255 to ~2^-48 relative and no f / 255 lies that close to a
     // rounding boundary: its bits beyond the mantissa repeat f's own eight; checked with exact rationals on the host, and
     // against k_phosphor_cc's table of IEEE quotients on the device: tests/test_parity_gpu.py::test_composite_triad_tables)
-    // (half frames: float(h) / 255.0f by norm_px's corrected reciprocal product — the IEEE quotient for every finite half, and k_phosphor_rr's
-    // own expression, so that the builds agree on non-finite samples too)
+    // Half frames: the same two instructions behind the conversion, with the pair split the OTHER way — c_hi = 1/255 rounded DOWN, c_lo > 0.  For
+    // every one of the 65 536 half bit patterns fma(f, c_hi, f * c_lo) is the IEEE quotient float(h) / 255.0f: correctly rounded for the finite
+    // ones, and with a positive c_lo the signed zeros, the infinities and NaN come out as the division gives them too (with the byte pair, whose
+    // c_lo is negative, -0 would turn into +0 and inf into NaN) — checked with exact rationals by tests/test_host_tables.py::
+    // test_half_quotient_constants_exact, and on the device against norm_px's form in k_phosphor_rr (test_fp16_column_owner_kernel).
     auto a1 = [&](uint32_t u) -> float {
-        if constexpr (HALF) return norm_px(CRTFX_PIX_F16, u);
+        if constexpr (HALF) {
+            const float fh = (float)__builtin_bit_cast(_Float16, (unsigned short)u);
+            return fmaf(fh, CT_HALF_C_HI, fh * CT_HALF_C_LO);
+        }
         const float fu = (float)u; return fmaf(fu, 0x1.010102p-8f, fu * -0x1.fdfdfep-33f);
     };
     // two bytes at once: the multiply and the fma as ONE packed instruction each (v_pk_mul_f32, v_pk_fma_f32) — the same two roundings per byte

@@ -228,3 +228,37 @@ def test_device_state_is_an_array_like():
     c = np.array(st)
     c[...] = 0.5
     assert c.flags.writeable and np.array_equal(st.tensor.numpy()[1:], ref[1:])
+
+
+def test_half_quotient_constants_exact():
+    """k_phosphor_ct<R, half> normalises a half sample as fma(f, C_HI, f * C_LO) (two instructions behind the conversion) instead of a division.
+    With the constants of the kernel source — C_HI = 1/255 rounded down, C_LO = float32(1/255 - C_HI) > 0 — that IS float32(h) / float32(255)
+    for every one of the 65 536 half bit patterns: exact rationals for the finite non-zero ones, IEEE special-case rules for zeros (sign kept),
+    infinities and NaN."""
+    import re
+    from fractions import Fraction
+    src = open(os.path.join(ROOT, "pythoncrt_amd", "csrc", "crtfx_phosphor_ct.hip.h")).read()
+    c_hi = float.fromhex(re.search(r"#define CT_HALF_C_HI (0x[0-9a-fp.+-]+)f", src).group(1))
+    c_lo = float.fromhex(re.search(r"#define CT_HALF_C_LO (0x[0-9a-fp.+-]+)f", src).group(1))
+    assert np.float32(c_hi) == c_hi and np.float32(c_lo) == c_lo and c_lo > 0 and Fraction(c_hi) < Fraction(1, 255)
+
+    def rn32(fr):
+        c = np.float32(float(fr))
+        cands = [np.nextafter(c, np.float32(-np.inf)), c, np.nextafter(c, np.float32(np.inf))]
+        return np.float32(min(cands, key=lambda x: (abs(Fraction(float(x)) - fr), int(np.float32(x).view(np.uint32)) & 1)))
+
+    hs = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    with np.errstate(all="ignore"):
+        ref = hs.astype(np.float32) / np.float32(255.0)
+        for h, want in zip(hs, ref):
+            f = np.float32(h)
+            p = np.float32(f * np.float32(c_lo))                                   # the separately rounded product (-ffp-contract=off)
+            if np.isfinite(f) and f != 0:
+                got = rn32(Fraction(float(f)) * Fraction(c_hi) + Fraction(float(p)))
+                assert got.view(np.uint32) == want.view(np.uint32), float(h)
+            elif np.isnan(f):
+                assert np.isnan(want)
+            elif f == 0:
+                assert p == 0 and np.signbit(p) == np.signbit(f) and np.signbit(want) == np.signbit(f)      # (+-0) * C_HI + (+-0): the sign survives only because C_LO > 0
+            else:
+                assert np.isinf(p) and np.signbit(p) == np.signbit(f) and want == f                           # inf * C_HI + inf (same sign): inf, not NaN
