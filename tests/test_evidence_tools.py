@@ -100,3 +100,33 @@ def test_bench_preflight_memory_estimate():
         assert need < 230 * gib, (name, need / gib)
     assert bench.preflight_need_bytes(2160, 3840, 400000, 1, 0.0, 1, 0) > 288 * gib
     assert bench.preflight_need_bytes(1080, 1920, 64, 1, 0.5, 2, 26) > bench.preflight_need_bytes(1080, 1920, 64, 1, 0.0, 2, 0)
+
+
+def test_committed_bench_lines_of_the_newest_round_carry_their_counters():
+    """Every committed per-config bench line of the newest round (profiles/rNN_z*_bench.json) was taken on the sources in the tree AFTER the
+    PMC passes of those sources had been summarised: `roofline.traffic` is a number, its provenance names the build's hash (not `stale`), the
+    bound is counter-derived and the plan is recorded.  Round 4 committed four lines that said `stale: true` / `bound: "hbm"`: the staleness
+    guard had worked, nobody had re-taken the lines.  (A change to any hashed source — pythoncrt_amd/csrc/*, include/crtfx.h — means: run
+    tools/collect_profiles.sh + summarise_profiles.py per config, then `bench.py --config N` again, and commit the five lines.)"""
+    import glob
+    import json
+    import re
+    import bench
+    rounds = sorted({int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_z*_bench.json"))
+                     for m in [re.match(r"r(\d+)_z", os.path.basename(f))] if m})
+    assert rounds, "no committed bench lines"
+    newest = rounds[-1]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r{newest:02d}_z*_bench.json")))
+    assert len(files) >= 5, files                      # the headline + configs 0, 2, 4, 5
+    now = bench.source_hash()
+    for f in files:
+        d = json.load(open(f))
+        r = d["roofline"]
+        src = r.get("traffic_source") or {}
+        assert not src.get("stale"), (os.path.basename(f), src)
+        assert src.get("source_hash") == now, (os.path.basename(f), src.get("source_hash"), now)
+        assert isinstance(r.get("traffic"), int) and r["traffic"] > 0 and r.get("fabric_frac"), os.path.basename(f)
+        assert r.get("valu") and r.get("bound_evidence", {}).get("fractions_of_each_limit"), os.path.basename(f)      # a counter-derived bound, not the "hbm" default
+        assert r.get("plan") and d.get("config", {}).get("workload"), os.path.basename(f)
+        if r.get("mall_ceiling") is not None:
+            assert "this box" in r["mall_ceiling"]["source"], os.path.basename(f)       # measured in the run, never a committed figure

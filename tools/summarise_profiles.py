@@ -32,7 +32,8 @@ try:
     pmc_batch = int(open(f"gpurun_out/{tag}_pmc_batch.txt").read().strip())      # frames per step of the PMC passes (tools/collect_profiles.sh)
 except (OSError, ValueError):
     pmc_batch = 8
-ks = newest(glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True))
+# (bench.py runs tools/ubench/mall_copy as a child process: under rocprofv3 that process leaves a kernel_stats.csv of its own — take the one with crtfx kernels)
+ks = newest([f for f in glob.glob(f"gpurun_out/{tag}_trace/**/*kernel_stats.csv", recursive=True) if "crtfx" in open(f).read()])
 if ks:
     rows = [r for r in csv.reader(open(ks[0]))]
     csv.writer(open(f"profiles/{tag}_kernel_stats.csv", "w")).writerows([rows[0]] + [r for r in rows[1:] if "crtfx" in r[0]])
