@@ -149,3 +149,57 @@ def test_random_full_chain_on_the_headline_kernel(case):
     assert d.max() <= 1 and (d != 0).mean() <= 2e-3, (case, rs, int(d.max()), float((d != 0).mean()))
     if rs.persistence > 0.0:
         assert np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_full_chain_on_the_half_kernel(case):
+    """The same draws for float16 frames (BASELINE configs[4]'s pixel format): everything that parks a pre-warp image — a warp or a persistence
+    blend behind the chain — runs k_phosphor_ct<R, half> (round 5: qword A phase, raw tile, centre samples in a register window), radii 1 .. 15,
+    every aberration, interior / edge / partial strips, a width that is not a multiple of four, a frame size that puts the batch's later frames off
+    a qword (33 x 641: the register-window kernel).  Frame by frame against the oracle's float image narrowed as the kernels narrow it
+    (|x * 255| in float32, then RNE to half).  No warp: frame 0 is the quantised pre-warp image — bit-exact; elsewhere the 8K test's bar."""
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    rng = np.random.default_rng(9000 + case)
+    pick = lambda *a: a[int(rng.integers(len(a)))]
+    h, w = CT_SIZES[case % len(CT_SIZES)]
+    warp = pick(0.0, 0.15, 0.15, -0.3)
+    rs = RenderSettings(
+        scanline_strength=pick(0.3, 0.6, 1.0), triad_strength=pick(0.2, 0.35, 0.5, 1.0), triad_gamma=pick(2.2, 1.8, 0.6), triad_preserve_luma=False,
+        triad_softness=pick(0.0, 0.5, 1.0, 2.0), aberration_px=int(rng.integers(-8, 9)), bloom_sigma=pick(0.2, 0.5, 1.0, 1.2, 2.0, 2.7, 3.0, 3.7, 4.0, 4.4, 4.6, 5.0),
+        bloom_strength=pick(0.1, 0.25, 0.9), bloom_threshold=0.0, noise_strength=pick(0.5, 1.5, 6.0), vignette_strength=pick(0.1, 0.25, 1.0),
+        persistence=(pick(0.2, 0.5) if warp == 0.0 else pick(0.0, 0.5)), scanline_speed_px_s=pick(30.0, -12.5, 7.0), scanline_period_px=pick(2.0, 3.7),
+        fast_bloom=False, pixel_size=1, warp_strength=warp)
+    n, first, fps, seed = 3, int(rng.integers(0, 40)), 25.0, int(rng.integers(1 << 40))
+    kind = rng.integers(3)
+    frames = (rng.random((n, h, w, 3), dtype=np.float32) * 255.0).astype(np.float16)             # fractional values on the 0..255 scale
+    if kind == 1:
+        frames[:] = ((np.arange(w, dtype=np.int64)[None, None, :, None] * 7 + np.arange(h)[None, :, None, None] * 3 + np.arange(3)[None, None, None, :] * 50) % 256).astype(np.float16)
+    elif kind == 2:
+        frames[:, :, : w // 2] = np.float16(255.0)      # saturated half: bloom clips, LUT index 1024
+        frames[:, ::5, w // 2:] = np.float16(0.0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=seed, dtype=torch.float16)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    want = "k_phosphor_ct<" if (h * w * 6) % 8 == 0 else "k_phosphor_rr<"
+    assert pipe.plan().get("phosphor", "").startswith(want) and pipe.plan()["phosphor"].endswith("half>"), pipe.plan()
+    got = out.cpu().numpy()
+    assert got.dtype == np.float16
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+                                          "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")}
+    st = None
+    for i in range(n):
+        p = torch.empty((h, w), dtype=torch.float32, device=dev)
+        assert pipe.lib.crtfx_noise_plane(pipe.engine.ctx, seed, first + i, p.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        _, st = orc.process_frames([frames[i]], params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness,
+                                   rs.vignette_strength, noise_planes=[p.cpu().numpy()], first_index=first + i, prev_state=st)
+        exp16 = np.abs(st.astype(np.float32) * np.float32(255.0)).astype(np.float16)
+        if warp == 0.0 and i == 0:
+            assert np.array_equal(got[0], exp16), (case, rs)
+        diff = np.abs(got[i].astype(np.float32) - exp16.astype(np.float32))
+        assert diff.max() <= 0.125 and (got[i] != exp16).mean() < 5e-3, (case, i, rs, float(diff.max()), float((got[i] != exp16).mean()))
+        if rs.persistence <= 0.0:
+            st = None
+    if rs.persistence > 0.0:
+        assert np.abs(state.cpu().numpy().astype(np.float64) - st).max() <= 1e-6
