@@ -195,9 +195,8 @@ _LIBC = None
 
 
 def _madvise(addr: int, length: int, advice: int) -> int:
-    """madvise(2) through ctypes: the call runs WITHOUT the GIL.  mmap.madvise of CPython 3.10 keeps it, and dropping the page-table entries
-    of an 8 MiB slice takes ~0.3 ms: issued from sixteen copy threads that way, the drops ran one after the other and held up every other
-    Python thread of the process — the 4K reader delivered 19 GB/s instead of 50 (profiles/r05_cli_throughput.txt)."""
+    """madvise(2) through ctypes: the call runs WITHOUT the GIL (mmap.madvise of CPython 3.10 keeps it), so the zapper thread's drops of a
+    400 MB batch (~13 ms) never hold up the Python threads that feed the GPU."""
     global _LIBC
     if _LIBC is None:
         import ctypes
@@ -270,9 +269,8 @@ class _MappedInput:
         def one(lo):
             hi = min(n, lo + _IO_SLICE)
             np.copyto(dst[lo:hi], self.arr[offset + lo:offset + hi])
-            # drop the page-table entries of what this thread has copied (the pages stay in the page cache), slice by slice on the I/O
-            # threads: unmapping a 24 GB clip's worth of touched pages in one piece at the end costs the render ~0.7 s, and zapping a
-            # whole batch from the reader thread 13 ms per 400 MB — on its critical path
+            # CRTFX_IO_DONTNEED=slice (round 4's form, kept for the A/B): drop the page-table entries of what this thread has copied, slice by
+            # slice on the I/O threads; the default hands the whole batch to the zapper thread below instead
             if drop is not None:
                 a0, a1 = ((offset + lo + page - 1) // page) * page, ((offset + hi) // page) * page
                 if a1 > a0:
@@ -929,7 +927,9 @@ def main(argv=None) -> int:
     # the output is opened with read access too (a MAP_SHARED, PROT_WRITE mapping needs O_RDWR).  An existing regular output file behind a
     # regular input file is NOT truncated at open: it is sized to the clip below, and the pages it already has in the page cache are
     # overwritten in place (registering them is several times faster than allocating new ones)
-    keep_pages = in_pos and out_path != "-" and os.path.isfile(out_path) and not os.path.samefile(out_path, a.input)
+    if in_pos and out_path != "-" and os.path.exists(out_path) and os.path.samefile(out_path, a.input):
+        raise SystemExit("--output is the input file")
+    keep_pages = in_pos and out_path != "-" and os.path.isfile(out_path)
     fout = sys.stdout.buffer if out_path == "-" else open(out_path, "r+b" if keep_pages else "w+b")
     out_pos = fout is not sys.stdout.buffer and _seekable(fout)
     pipe_in, pipe_out = (0 if in_pos else _grow_pipe(fin)), (0 if out_pos else _grow_pipe(fout))      # pipes: the largest buffer the kernel allows
