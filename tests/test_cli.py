@@ -122,3 +122,77 @@ def test_cli_pipes_get_the_large_buffer():
             assert cli._grow_pipe(f) == 0
     finally:
         pass
+
+
+def test_registered_map_windows(tmp_path, monkeypatch):
+    """cli._RegisteredMap (the --io mapped path) without a GPU: hipHostRegister / Unregister / MemcpyAsync replaced by recorders.  Windows sit on a
+    fixed grid, a window two batches share is registered once and unregistered when the second one lets go, a refused registration leaves nothing
+    registered for that call, and a copy is issued window by window (the runtime rejects one that runs across two registrations)."""
+    calls = []
+    refuse = set()
+
+    class FakeDma:
+        H2D, D2H = 1, 2
+
+        @staticmethod
+        def register(ptr, n):
+            if ptr in refuse:
+                return False
+            calls.append(("reg", ptr, n))
+            return True
+
+        @staticmethod
+        def unregister(ptr):
+            calls.append(("unreg", ptr))
+
+        @staticmethod
+        def copy(dst, src, n, kind, stream):
+            calls.append(("copy", dst, src, n, kind))
+    monkeypatch.setattr(cli, "_HostDma", FakeDma)
+    monkeypatch.setattr(cli._RegisteredMap, "WIN", 64 * 1024)
+    win = 64 * 1024
+    size = 5 * win + 1234
+    path = tmp_path / "f.bin"
+    path.write_bytes(os.urandom(size))
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        m = cli._RegisteredMap(fd, size, writable=False)
+        base = m.base
+        # batch A: bytes [10 000, 150 000) = windows 0, 1, 2
+        assert m.acquire(10_000, 140_000)
+        assert [c for c in calls if c[0] == "reg"] == [("reg", base, win), ("reg", base + win, win), ("reg", base + 2 * win, win)]
+        # batch B: [150 000, 300 000) = windows 2, 3, 4: window 2 is shared and not registered again
+        calls.clear()
+        assert m.acquire(150_000, 150_000)
+        assert [c[1] for c in calls if c[0] == "reg"] == [base + 3 * win, base + 4 * win]
+        # the copy of batch B runs window by window, contiguous on both sides
+        calls.clear()
+        m.copy(FakeDma.H2D, 1 << 40, 150_000, 150_000, 0)
+        cp = [c for c in calls if c[0] == "copy"]
+        assert [c[3] for c in cp] == [3 * win - 150_000, win, 300_000 - 4 * win] and sum(c[3] for c in cp) == 150_000
+        assert cp[0][1] == 1 << 40 and cp[0][2] == base + 150_000 and cp[1][1] == (1 << 40) + cp[0][3] and cp[1][2] == base + 3 * win
+        calls.clear()
+        m.copy(FakeDma.D2H, 1 << 40, 10_000, 100, 0)                      # device -> file: destination is the mapping
+        assert calls == [("copy", base + 10_000, 1 << 40, 100, FakeDma.D2H)]
+        # releasing A frees windows 0 and 1; window 2 stays for B
+        calls.clear()
+        m.release(10_000, 140_000)
+        assert calls == [("unreg", base), ("unreg", base + win)]
+        calls.clear()
+        m.release(150_000, 150_000)
+        assert calls == [("unreg", base + 2 * win), ("unreg", base + 3 * win), ("unreg", base + 4 * win)] and m.ref == {}
+        # the last window is clipped to the mapping's page-rounded length
+        calls.clear()
+        assert m.acquire(5 * win + 10, 1000)
+        assert calls == [("reg", base + 5 * win, m.maplen - 5 * win)] and m.maplen % 4096 == 0 and m.maplen >= size
+        m.release(5 * win + 10, 1000)
+        # a refused window: what this call had registered is rolled back, what another batch holds stays
+        assert m.acquire(0, 10)
+        calls.clear()
+        refuse.add(base + 2 * win)
+        assert not m.acquire(10, 2 * win + 10)                             # windows 0 (held), 1 (new), 2 (refused)
+        assert calls == [("reg", base + win, win), ("unreg", base + win)] and m.ref == {0: 1}
+        m.close()
+        assert ("unreg", base) in calls and m.ref == {}
+    finally:
+        os.close(fd)
