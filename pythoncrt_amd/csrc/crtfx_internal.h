@@ -9,7 +9,8 @@ namespace crtfx {
 // One per radius, each in its own translation unit (crtfx_rr.hip compiled with -DRR_R=n) so the
 // thirty sets of instantiations build in parallel.  variant: 0 = runtime gates (uint8), 1 = SF_FULL gates folded (uint8), 2 = SF_FULL + half frames, 3 = runtime gates + half frames,
 // 4 = k_phosphor_cc (SF_FULL gates, uint8 frames, pre-warp image out), 5 = SF_FULL + pixelate gates folded (uint8),
-// 6 = k_phosphor_ct (as 4: composite triad tables, centre samples from the frame, scalar row tables).
+// 6 = k_phosphor_ct (as 4: composite triad tables, centre samples from the frame, scalar row tables), 7 = k_phosphor_ct<R, half> (as 6 for half frames: qword loads,
+// a one-trip raw tile, the centre samples in a register window).
 using rr_launch_fn = void (*)(const KParams&, const KGroup&, int seg_rows, dim3 grid, size_t lds, hipStream_t, int variant,
                               hipEvent_t ev_start, hipEvent_t ev_stop);
 

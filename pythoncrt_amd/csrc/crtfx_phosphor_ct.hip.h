@@ -330,23 +330,29 @@ __global__ __launch_bounds__(RR_THREADS, ct_min_waves(RT)) void k_phosphor_ct(KP
 #pragma unroll
             for (int i = 0; i < (HALF ? (NW + 1) / 2 : 1); ++i) cw[i] = 0u;
             auto cw_take = [&](float (&v)[NB]) {
+                if constexpr (HALF) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) v[j] = a1((j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xFFFFu);
+                    for (int j = 0; j < NB; ++j) v[j] = a1((j & 1) ? cw[j >> 1] >> 16 : cw[j >> 1] & 0xFFFFu);
+                }
             };
             auto cw_shift = [&]() {
+                if constexpr (HALF) {
 #pragma unroll
-                for (int i = 0; i < (R + 1) / 2; ++i) cw[i] = cw[i + NB / 2];
+                    for (int i = 0; i < (R + 1) / 2; ++i) cw[i] = cw[i + NB / 2];
+                }
             };
             auto cw_append = [&]() {
-                uint32_t hs[NB];
+                if constexpr (HALF) {
+                    uint32_t hs[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) hs[j] = (uint32_t)LDS_AT(lds_u16_t, RING_B + (uint32_t)(j * TW * 8) + cpl);
+                    for (int j = 0; j < NB; ++j) hs[j] = (uint32_t)LDS_AT(lds_u16_t, RING_B + (uint32_t)(j * TW * 8) + cpl);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int i = R + j;
-                    if ((i & 1) == 0 && j + 1 < NB) cw[i >> 1] = hs[j] | (hs[j + 1] << 16);
-                    else if ((i & 1) == 0) cw[i >> 1] = hs[j];      // the window's last element: its upper half is unused
-                    else if (j == 0) cw[i >> 1] = (cw[i >> 1] & 0xFFFFu) | (hs[0] << 16);      // R odd: element R shares its VGPR with element R - 1
+                    for (int j = 0; j < NB; ++j) {
+                        const int i = R + j;
+                        if ((i & 1) == 0 && j + 1 < NB) cw[i >> 1] = hs[j] | (hs[j + 1] << 16);
+                        else if ((i & 1) == 0) cw[i >> 1] = hs[j];      // the window's last element: its upper half is unused
+                        else if (j == 0) cw[i >> 1] = (cw[i >> 1] & 0xFFFFu) | (hs[0] << 16);      // R odd: element R shares its VGPR with element R - 1
+                    }
                 }
             };
             f32x2 win2[L / 2];
