@@ -52,6 +52,7 @@ case_() {  # label input output io [keep-output-between-runs]
 ts, tl, ns, nl = float("$ts" or "nan"), float("$tl" or "nan"), $NS, $NL
 print(f"  $label: {ns} frames {ts:.3f} s, {nl} frames {tl:.3f} s -> steady state {(nl - ns) / (tl - ts):.0f} frames/s")
 PY
+  grep "staging: pipeline" $LOG | sed 's/^staging: /      in-process: /'
   grep staging $LOG | sed 's/^/      /'
 }
 for io in staged mapped auto; do case_ "file -> /dev/null, --io $io" file /dev/null $io; done
