@@ -535,9 +535,13 @@ class _Reader:
                     self.mode = "mapped"
                 except (OSError, ValueError, AttributeError) as e:
                     self.note = f"input mapping refused ({e.__class__.__name__}): staged"
+        self._pin_lock = threading.Lock()
         if self.mode == "staged":
+            # pinned up front, as the GPU loop expects when it starts.  (Six 16-frame 4K slots take 0.5 s of hipHostMalloc; pinning all but the
+            # first on a helper thread beside the first batches was tried in round 5: the pipeline then ran 0.25 s longer — the runtime
+            # serialises the allocations with the copies' enqueues — and the run as a whole no shorter.)
             for i in range(slots):
-                self._buf(i)                   # pinned up front, as the GPU loop expects when it starts
+                self._buf(i)
 
         def stage(i, off, nfr):
             view = memoryview(self._buf(i).numpy()).cast("B")[: nfr * frame_bytes]
@@ -601,7 +605,9 @@ class _Reader:
 
     def _buf(self, i):
         if self._bufs[i] is None:
-            self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
+            with self._pin_lock:
+                if self._bufs[i] is None:
+                    self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
         return self._bufs[i]
 
     @property
@@ -656,6 +662,7 @@ class _Writer:
         import torch
         self._torch, self.shape, self.frame_bytes = torch, shape, frame_bytes
         self._bufs = [None] * slots
+        self._pin_lock = threading.Lock()
         self.free, self.work = queue.Queue(), queue.Queue()
         for i in range(slots):
             self.free.put(i)
@@ -731,7 +738,9 @@ class _Writer:
 
     def _buf(self, i):
         if self._bufs[i] is None:
-            self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
+            with self._pin_lock:
+                if self._bufs[i] is None:
+                    self._bufs[i] = self._torch.empty(self.shape, dtype=self._torch.uint8).pin_memory()
         return self._bufs[i]
 
     @property
@@ -910,9 +919,11 @@ def main(argv=None) -> int:
     if a.width <= 0 or a.height <= 0:
         raise SystemExit("raw rgb24 input needs --width and --height")
     import os
+    t_start = time.perf_counter()
     import torch
     from .pipeline import FramePipeline
     from .text import make_text_overlay_rgba
+    t_imports = time.perf_counter() - t_start
     rs = settings_from_args(a)
     fps_out = int(a.fps) if a.fps and a.fps > 0 else 24            # ref:914
     h, w = int(a.height), int(a.width)
@@ -922,6 +933,7 @@ def main(argv=None) -> int:
     seed = a.noise_seed if a.noise_seed is not None else int.from_bytes(os.urandom(8), "little")
     overlay = make_text_overlay_rgba(w, h, a.text, a.text_font, a.text_size, a.text_color, (a.text_x, a.text_y)) if a.text else None   # ref:1076
     pipe = FramePipeline(dev, h, w, rs, fps=fps_out, noise_seed=seed, text_overlay_rgba=overlay, text_overlay_after=bool(a.text_after))
+    t_engine = time.perf_counter() - t_start - t_imports
     fin = sys.stdin.buffer if a.input == "-" else open(a.input, "rb", buffering=0)
     out_path = a.output if a.output else (a.input + "_crt.rgb" if a.input != "-" else "-")
     B = max(1, int(a.batch))
@@ -955,6 +967,7 @@ def main(argv=None) -> int:
     reader = _Reader(fin, in_pos, jobs(), (B, h, w, 3), frame_bytes, slots=NS, io=a.io, autostart=False)
     writer = _Writer(fout, out_pos, (B, h, w, 3), frame_bytes, slots=NS, plan=out_plan, io=a.io)
     t_pipe = time.perf_counter()                                    # the pipeline proper: first read issued ... last batch written (the --staging-report line)
+    t_slots = t_pipe - t_start - t_imports - t_engine
     reader.start()
     dev_in = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
     dev_out = [torch.empty((B, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(NS)]
@@ -1056,6 +1069,7 @@ def main(argv=None) -> int:
         # start-up (imports, ctx, tables, pinning the staging slots) and the exit are outside this figure; the reader's first read, the unoverlapped
         # legs of the first and last batch and the output's last write are inside it
         print(f"staging: pipeline {index} frames in {t_pipe:.3f} s = {index / max(t_pipe, 1e-9):.0f} frames/s (first read issued ... last batch written)", file=sys.stderr)
+        print(f"staging: start-up imports {t_imports:.3f} s, device + ctx + tables {t_engine:.3f} s, files + staging slots {t_slots:.3f} s", file=sys.stderr)
         print(f"staging: input {reader.mapped_batches} batches mapped (hipHostRegister {reader.rmap.t_reg if reader.rmap else 0.0:.3f}s), {reader.staged_batches} staged"
               f"{' — ' + reader.note if reader.note else ''} | output {writer.mapped_batches} batches mapped (register + page allocation {writer.t_prep:.3f}s)"
               f"{' — ' + writer.note if writer.note else ''} | pipe buffers in {pipe_in} out {pipe_out} bytes", file=sys.stderr)
