@@ -196,3 +196,32 @@ def test_registered_map_windows(tmp_path, monkeypatch):
         assert ("unreg", base) in calls and m.ref == {}
     finally:
         os.close(fd)
+
+
+def test_process_frames_takes_process_video_keywords():
+    """pythoncrt_amd.process_frames — the drop-in for the loop of process_video (ref:1037-1131) — accepts every keyword process_video itself
+    takes (tests/golden/reference_cli.json holds the reference's own parameter list): the effect keywords by name with the CLI's defaults, the
+    container / codec ones (input_path, crf, nvenc_preset, ...) swallowed, anything else refused; its leading parameters are the things the
+    reference's loop already holds (frame iterator, writer call, output size, fps, total_frames)."""
+    import inspect
+    import pythoncrt_amd as pc
+    from pythoncrt_amd import render
+    sig = inspect.signature(pc.process_frames)
+    names = list(sig.parameters)
+    assert names[:6] == ["frame_iter", "write_frame", "out_w", "out_h", "fps_out", "total_frames"]
+    ref = FX["process_video_kwargs"]["defaults"]
+    io_keys = set(render._IO_KEYS)
+    for k, v in ref.items():
+        if k in io_keys:
+            assert k not in sig.parameters
+            continue
+        p = sig.parameters[k]
+        assert p.kind is inspect.Parameter.KEYWORD_ONLY, k
+        if k == "text_pos":
+            assert tuple(p.default) == tuple(v)
+        elif k == "text_after":
+            assert p.default is True                          # process_video's own default (ref:910); the CLI passes its flag, off by default (ref:1199)
+        elif k != "progress_cb":
+            assert p.default == v, (k, p.default, v)          # = what process_video receives when the CLI is run with no flags
+    assert set(ref) - io_keys <= set(names)
+    assert sig.parameters["io_keywords"].kind is inspect.Parameter.VAR_KEYWORD

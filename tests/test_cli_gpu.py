@@ -332,3 +332,49 @@ def test_bench_preflight_fails_fast_with_a_reason(case):
     assert r.returncode != 0 and took < 60, (r.returncode, took, r.stderr[-1500:])
     assert "bench.py preflight failed" in r.stderr and want in r.stderr, r.stderr[-1500:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no result line
+
+
+@pytest.mark.parametrize("case", ["defaults", "gaussian_warp_text", "no_persistence_resized"])
+def test_process_frames_is_the_render_loop(pc, case):
+    """pythoncrt_amd.process_frames — the loop of process_video (ref:1037-1131) over the caller's own frame iterator and writer call: frames
+    in order, frame i at phase i / fps * speed, persistence carried across its batches, a frame of another size resized with Pillow first
+    (ref:1039-1041), progress_cb after every frame (ref:1104-1105), text overlay built once.  Same bytes as one FramePipeline.run over the whole
+    clip, and the oracle's in-order render within the usual bar."""
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    from pythoncrt_amd.text import make_text_overlay_rgba
+    n, h, w, fps = 11, 72, 128, 25
+    frames = list(clip(n, h, w, 77))
+    kw = {"defaults": dict(noise_strength=0.0),
+          "gaussian_warp_text": dict(fast_bloom=False, bloom_sigma=2.0, pixel_size=1, warp_strength=0.15, persistence=0.5, noise_strength=0.0,
+                                     text="CRT", text_size=20, text_pos=(8, 8), text_after=True, text_color="#FFCC00"),
+          "no_persistence_resized": dict(persistence=0.0, noise_strength=0.0, fast_bloom=False, bloom_sigma=1.2, pixel_size=1)}[case]
+    feed = list(frames)
+    if case == "no_persistence_resized":
+        from PIL import Image
+        big = np.asarray(Image.fromarray(frames[4]).resize((w * 2, h * 2), Image.BILINEAR))      # a frame of another size in the stream
+        feed[4] = big
+        frames[4] = np.asarray(Image.fromarray(big).resize((w, h), Image.BILINEAR))              # what the loop makes of it (ref:1039-1041)
+    got, prog = [], []
+    written = pc.process_frames(iter(feed), lambda a: got.append(np.array(a)), w, h, fps, n, batch=4, noise_seed=5, progress_cb=prog.append,
+                                crf=18, nvenc_preset="p4", input_path="x.mp4", **kw)
+    assert written == n and len(got) == n and all(g.shape == (h, w, 3) and g.dtype == np.uint8 for g in got)
+    assert prog == [min(1.0, (i + 1) / n) for i in range(n)]
+    # the same clip in one piece
+    fx = {k: v for k, v in kw.items() if not k.startswith("text")}
+    rs = RenderSettings(**fx)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ov = make_text_overlay_rgba(w, h, kw["text"], "", kw["text_size"], kw["text_color"], kw["text_pos"]) if "text" in kw else None
+    pipe = FramePipeline(dev, h, w, rs, fps=fps, noise_seed=5, text_overlay_rgba=ov, text_overlay_after=kw.get("text_after", True))
+    direct, _ = pipe.run(torch.from_numpy(np.stack(frames)).to(dev))
+    assert np.array_equal(np.stack(got), direct.cpu().numpy())
+    # ... and the oracle's in-order loop
+    params = {k: getattr(rs, k) for k in ("scanline_strength", "triad_gamma", "triad_preserve_luma", "aberration_px", "bloom_sigma", "bloom_strength",
+                                          "bloom_threshold", "noise_strength", "scanline_period_px", "fast_bloom", "pixel_size", "warp_strength")}
+    if ov is not None:
+        params.update(text_overlay_rgba=ov, text_overlay_after=True)
+    exp, _ = orc.process_frames(frames, params, fps, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength, rs.triad_softness, rs.vignette_strength)
+    d = np.abs(np.stack(got).astype(np.int16) - np.stack(exp).astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (case, int(d.max()), float((d != 0).mean()))
+    # a keyword that is neither an effect nor one of process_video's I/O keywords is refused
+    with pytest.raises(TypeError):
+        pc.process_frames(iter(feed), lambda a: None, w, h, fps, n, scanlines=0.5)
