@@ -469,6 +469,24 @@ __device__ __forceinline__ void store_row_f16_buf(__amdgpu_buffer_rsrc_t rs, uin
         __builtin_amdgcn_raw_buffer_store_b32(dw, rs, off, 0, AUX);
     }
 }
+// ... and as whole QWORDS: ONE store instruction per wave and row instead of two (the texture-address unit is busy per instruction, whatever its
+// width, and k_warp_lean<half> keeps it 82 % busy: profiles/r05_c5_vmem.json).  Needs a row segment of a multiple of four pixels (24 bytes =
+// three qwords; the launcher checks W % 4 == 0).  Qword q = dwords 2q, 2q + 1 of the segment; with the dword map above the three lanes of a
+// period take their two dwords from pixel pairs (4g, 4g + 1), (4g + 1, 4g + 2), (4g + 2, 4g + 3): four cross-lane reads per lane.
+template <int AUX = 0>
+__device__ __forceinline__ void store_row_f16_buf64(__amdgpu_buffer_rsrc_t rs, uint32_t row_byte0, int lane, int valid_px, PackedPix pk) {
+    const int g = lane / 3, t = lane - 3 * g;                  // lanes 0 .. 47: qword = lane
+    const int pa = (4 * g + t) & 63, pb = (4 * g + t + 1) & 63;
+    const uint32_t la = __shfl(pk.lo, pa), ha = __shfl(pk.hi, pa), lb = __shfl(pk.lo, pb), hb = __shfl(pk.hi, pb);
+    // t = 0: dwords 6g, 6g + 1 = lo[4g] , hi[4g] | lo[4g+1] << 16
+    // t = 1: dwords 6g + 2, 6g + 3 = lo[4g+1] >> 16 | hi[4g+1] << 16 , lo[4g+2]
+    // t = 2: dwords 6g + 4, 6g + 5 = hi[4g+2] | lo[4g+3] << 16 , lo[4g+3] >> 16 | hi[4g+3] << 16
+    const uint32_t d0 = t == 0 ? la : (t == 1 ? ((la >> 16) | (ha << 16)) : ((ha & 0xFFFFu) | (lb << 16)));
+    const uint32_t d1 = t == 0 ? ((ha & 0xFFFFu) | (lb << 16)) : (t == 1 ? lb : ((lb >> 16) | (hb << 16)));
+    const uint32_t off = (lane < 48 && 8 * lane + 8 <= valid_px * 6) ? row_byte0 + 8u * (uint32_t)lane : 0xFFFFFFF0u;
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{d0, d1}, rs, off, 0, AUX);
+}
 __device__ __forceinline__ void store_row_pix(const KOut& O, size_t row_px0, int lane, int valid_px, PackedPix pk) {
     if (O.pix == CRTFX_PIX_F16) store_row_f16(O.out_u8, row_px0, lane, valid_px, pk);
     else store_row_u8(O.out_u8, row_px0 * 3, lane, valid_px, pk.lo);

@@ -261,9 +261,12 @@ __global__ __launch_bounds__(256) void k_warp_lean(KParams P, KWarpGroup G, int 
             if constexpr (BLEND == CRTFX_BLEND_RENDER) st[r] = F3{f0, f1, f2};
             if constexpr (PLAIN) {
                 // row y >= H: its byte offset is >= the buffer's size: every dword of the row is dropped
-                if constexpr (PIX == CRTFX_PIX_F16)
-                    store_row_f16_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 6u) + (uint32_t)x0 * 6u, lane, min(64, P.W - x0),
-                                         PackedPix{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)});
+                if constexpr (PIX == CRTFX_PIX_F16) {
+                    const PackedPix pk{quant_f16(f0) | (quant_f16(f1) << 16), quant_f16(f2)};
+                    const uint32_t rb = __umul24((uint32_t)y, (uint32_t)P.W * 6u) + (uint32_t)x0 * 6u;
+                    if ((P.W & 3) == 0) store_row_f16_buf64<2>(out_rs, rb, lane, min(64, P.W - x0), pk);      // kernel-argument-uniform: whole qwords, one store per row
+                    else store_row_f16_buf<2>(out_rs, rb, lane, min(64, P.W - x0), pk);
+                }
                 else
                     store_row_u8_buf<2>(out_rs, __umul24((uint32_t)y, (uint32_t)P.W * 3u) + (uint32_t)x0 * 3u, lane, min(64, P.W - x0), quant_u8x3(f0, f1, f2), true);
                 continue;
