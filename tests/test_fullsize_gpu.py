@@ -115,7 +115,8 @@ def test_fp16_wide_frames_against_oracle(dev, ab, hw, sigma):
 
 @pytest.mark.parametrize("ab,hw,sigma", [(1, (40, 448), 3.0), (0, (33, 704), 1.2), (-3, (40, 448), 3.0), (8, (24, 640), 4.0), (-8, (40, 320), 3.0), (2, (60, 256), 0.4),
                                          (1, (30, 449), 3.0), (1, (40, 450), 3.0), (-1, (37, 708), 2.0), (5, (1100, 128), 3.3), (1, (520, 1024), 3.0),
-                                         (1, (40, 448), 4.4), (-2, (48, 512), 4.6), (3, (64, 576), 5.0)])      # radii 13 - 15: the half build with spilled registers
+                                         (1, (40, 448), 4.4), (-2, (48, 512), 4.6), (3, (64, 576), 5.0),      # radii 13 - 15: the half build with spilled registers
+                                         (1, (36, 100), 3.0), (-2, (28, 212), 1.2)])      # last strips of 36 / 20 pixels: partial qword rows out of k_warp_lean
 def test_fp16_column_owner_kernel(dev, ab, hw, sigma, monkeypatch):
     """Round 5: half frames that park a pre-warp image (warp on) run k_phosphor_ct<R, half> — frame-row windows as aligned qwords, the raw units of a
     trip in a one-trip LDS tile, each consumer thread's centre samples in a register window of packed halves.  Every aberration sign and size,
