@@ -75,6 +75,9 @@ int main(int argc, char** argv) {
     unsigned long long sum = 0;
     for (unsigned char v : out) sum += v;
     std::printf("crtfx ABI v%d: %d frames of %dx%d, output checksum %llu\n", crtfx_version(), N, W, H, sum);
+    char plan[256];
+    CRTCHK(crtfx_last_plan(ctx, plan, sizeof plan));          // which kernel builds the call above landed on
+    std::printf("plan: %s\n", plan);
     (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_state); (void)hipStreamDestroy(s);
     crtfx_destroy(ctx);
     return 0;

@@ -266,6 +266,7 @@ def test_c_abi_consumer(pc, tmp_path):
     r = subprocess.run([exe, str(fin), str(w), str(h), str(n), str(fout)], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "frames of 128x72" in r.stdout
+    assert "plan: point=k_point" in r.stdout and ";warp=k_warp" in r.stdout, r.stdout          # crtfx_last_plan from plain C
     got = np.frombuffer(fout.read_bytes(), dtype=np.uint8).reshape(n, h, w, 3)
     rs = RenderSettings(scanline_strength=0.0, triad_strength=0.0, aberration_px=2, bloom_strength=0.0, noise_strength=0.0,
                         vignette_strength=0.4, persistence=0.5, fast_bloom=False, pixel_size=1, warp_strength=0.2)
