@@ -225,3 +225,15 @@ def test_process_frames_takes_process_video_keywords():
             assert p.default == v, (k, p.default, v)          # = what process_video receives when the CLI is run with no flags
     assert set(ref) - io_keys <= set(names)
     assert sig.parameters["io_keywords"].kind is inspect.Parameter.VAR_KEYWORD
+
+
+def test_process_frames_fails_loudly_without_a_gpu():
+    """No CPU fallback in the product path: without a ROCm device process_frames raises (and a misspelt keyword is refused before anything else)."""
+    import pytest
+    import torch
+    import pythoncrt_amd as pc
+    with pytest.raises(TypeError):
+        pc.process_frames(iter([]), lambda a: None, 8, 8, 30, 1, scanlines=1.0)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no ROCm device"):
+            pc.process_frames(iter([np.zeros((8, 8, 3), np.uint8)]), lambda a: None, 8, 8, 30, 1)
