@@ -7,7 +7,7 @@ See DESIGN.md (path, kernels, roofline) and INTEGRATION.md (how the reference bi
 """
 from .effects import (DeviceState, TriadMask, VignetteMask, apply_crt_effect, apply_static_effects, make_triad_mask,
                       make_vignette)
-from .render import process_frames
+from .render import iter_rgb24, process_frames
 
 __all__ = ["DeviceState", "TriadMask", "VignetteMask", "apply_crt_effect", "apply_static_effects", "make_triad_mask", "make_vignette",
-           "process_frames"]
+           "process_frames", "iter_rgb24"]

@@ -25,6 +25,24 @@ _IO_KEYS = ("input_path", "output_path", "width", "height", "fps", "crf", "targe
             "decoder_preference")
 
 
+def iter_rgb24(stream, out_w: int, out_h: int):
+    """The frame iterator of the reference's FFmpegRawReader.iter_frames (ref:495-506) over an ALREADY OPEN byte stream of raw rgb24 — the
+    stdout of an ffmpeg process the caller started (`-f rawvideo -pix_fmt rgb24 -`), a file, a pipe: frames of out_h x out_w x 3 uint8 until the
+    stream ends; a trailing partial frame is dropped, as there.  (The reader class itself — spawning ffmpeg, hw-accel flags — is codec plumbing
+    and stays the reference's.)"""
+    frame_size = int(out_w) * int(out_h) * 3
+    while True:
+        buf = stream.read(frame_size)
+        while buf and len(buf) < frame_size:           # a pipe may return less than asked for: keep reading until the frame is whole or the stream ends
+            more = stream.read(frame_size - len(buf))
+            if not more:
+                break
+            buf += more
+        if not buf or len(buf) < frame_size:
+            return
+        yield np.frombuffer(buf, dtype=np.uint8).reshape((int(out_h), int(out_w), 3))
+
+
 def process_frames(frame_iter: Iterable[np.ndarray], write_frame: Callable[[np.ndarray], None], out_w: int, out_h: int, fps_out: float,
                    total_frames: Optional[int] = None, *,
                    scanline_strength: float = 0.6, triad_strength: float = 0.35, triad_gamma: float = 2.2, triad_preserve_luma: bool = False,

@@ -237,3 +237,27 @@ def test_process_frames_fails_loudly_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no ROCm device"):
             pc.process_frames(iter([np.zeros((8, 8, 3), np.uint8)]), lambda a: None, 8, 8, 30, 1)
+
+
+def test_iter_rgb24_is_the_raw_readers_iteration():
+    """pythoncrt_amd.iter_rgb24 = FFmpegRawReader.iter_frames (ref:495-506) over an open stream: whole frames in order, a trailing partial frame
+    dropped, short reads of a pipe reassembled."""
+    import io
+    import pythoncrt_amd as pc
+    h, w, n = 5, 7, 4
+    data = np.arange(n * h * w * 3, dtype=np.uint32).astype(np.uint8).tobytes()
+    got = list(pc.iter_rgb24(io.BytesIO(data + b"\x01\x02\x03"), w, h))
+    assert len(got) == n and all(g.shape == (h, w, 3) and g.dtype == np.uint8 for g in got)
+    assert b"".join(g.tobytes() for g in got) == data
+
+    class Dribble:                                      # a pipe that hands out at most 11 bytes per read
+        def __init__(self, b):
+            self.b, self.p = b, 0
+
+        def read(self, k):
+            out = self.b[self.p:self.p + min(k, 11)]
+            self.p += len(out)
+            return out
+    got2 = list(pc.iter_rgb24(Dribble(data), w, h))
+    assert len(got2) == n and b"".join(g.tobytes() for g in got2) == data
+    assert list(pc.iter_rgb24(io.BytesIO(b""), w, h)) == []
