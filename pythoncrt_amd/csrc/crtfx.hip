@@ -582,6 +582,7 @@ int run_chain(crtfx_ctx* c, const void* in, const crtfx_frame* f, KOut ko, hipSt
             }
         }
         ProfEv pe(c, 0);
+        c->plan.group = 1;                                               // one frame per launch on this path (crtfx_last_plan)
         const int waves = c->point_tiles > 0 ? c->point_tiles : 8;       // rows per block (CRTFX_POINT_TILES): 1080p 4 rows 34.8 us, 8 rows 32.9, 16 rows 37.5
         dim3 grid((c->W + TW - 1) / TW, (c->H + waves - 1) / waves);
         const uint32_t gates = fl & ~(uint32_t)CRTFX_F_WARP;
