@@ -283,6 +283,24 @@ def backend_version(backend):
         return f"unknown ({e.__class__.__name__})"
 
 
+class stdout_to_stderr:
+    """File-descriptor-level redirect of stdout to stderr for the duration of the block.  RCCL 2.26 prints a five-line banner ("RCCL version :
+    ...", HIP / ROCm versions, host name, library path) on STDOUT from rank 0 when its first communicator comes up — measured on the one-GPU
+    box in round 6 (profiles/r06_rccl_world1.json's run) — and the contract of this program is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -305,6 +323,9 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=2, help="further timed regions of K steps after the reported one (spread only; 0 = none)")
     ap.add_argument("--tables-outside", action="store_true", help="build the per-frame host tables before the timed region (A/B of the host share)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py launches the ranks itself")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: take the N > 1 code path at world size 1 — init_process_group over RCCL, the barrier / all_reduce / "
+                         "all_gather calls, and (config 4) the sharded-persistence schedule as the one-rank ring, its hop a real isend / irecv to itself")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="libcrtfx testing/tuning switch (crtfx_set_option), e.g. NO_CC=1; never part of a reported result")
     return ap.parse_args(argv)
 
@@ -347,8 +368,11 @@ def main():
         self_launch(a)                      # never returns
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.force_dist and world != 1:
+        raise SystemExit("--force-dist is the world-size-1 rehearsal of the N > 1 path (use --gpus N for N > 1)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
+    use_dist = world > 1 or a.force_dist
     backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl")      # "gloo": rehearsal of several ranks on fewer GPUs (never a result)
 
     from pythoncrt_amd import effects
@@ -364,7 +388,7 @@ def main():
     B_plan = a.batch or (384 if h >= 4320 else 1920 if h >= 2160 else 8192)
     if p > 0.0 and not a.batch:
         B_plan = max(settle_frames(p), 4096 if world > 1 else 8192)
-    why = preflight(a, world, rank, local_rank, backend, h, w, B_plan, 2 if a.config == 5 else 1, p, 2 if (p > 0.0 and world > 1) else 1,
+    why = preflight(a, world, rank, local_rank, backend, h, w, B_plan, 2 if a.config == 5 else 1, p, 2 if (p > 0.0 and use_dist) else 1,
                     min(B_plan, settle_frames(p, 2.0 ** -26)) if p > 0.0 else 0)
     if why:
         print(f"bench.py preflight failed: {why}", file=sys.stderr, flush=True)
@@ -372,14 +396,21 @@ def main():
     device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    if use_dist:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:          # --force-dist with no launcher around it: a free port of our own
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         # a rank that never arrives (it failed its pre-flight, or was never started) must not leave the others at the rendezvous for the
         # default half hour: one minute, then init_process_group raises and the job ends non-zero
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("CRTFX_RENDEZVOUS_TIMEOUT_S", "60"))),
-                                **({"device_id": device} if backend == "nccl" else {}))
+        with stdout_to_stderr():     # the communicator comes up here (device_id: eager) or at the first collective: both inside the redirect
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("CRTFX_RENDEZVOUS_TIMEOUT_S", "60"))),
+                                    **({"device_id": device} if backend == "nccl" else {}))
+            dist.barrier()
     # frames per step: enough that the default 20 steps run >= 3 s — a timed region the driver's 5-s GPU-busy sampler
     # cannot miss (4K: 1920 frames = 47.8 GB in + 47.8 GB out of the 288 GB; 1080p: 8192 frames = 51 GB each way; 8K fp16:
     # 384 frames = 76.4 GB each way).  Sharded persistence needs B >= settle_frames(p) anyway (shard.py); per-frame states
@@ -391,13 +422,13 @@ def main():
     pipe = FramePipeline(device, h, w, rs, fps=fps, noise_seed=1234, dtype=dtype)
     frames = synth_frames(B, h, w, device, seed=1234 + 1000 * rank).to(dtype)
     shard = FrameShard(world, rank, B)
-    sharded_iir = p > 0.0 and world > 1
+    sharded_iir = p > 0.0 and use_dist
     engine = GpuShardEngine(pipe, B, slots=2 if sharded_iir else 1)
     # the overlapped hop schedule is the default over gloo (rehearsals) only: its RCCL branch has never run on hardware
     # (no multi-GPU box in this pipeline), and at these chunk sizes the synchronous hop costs < 2 % of a round
     # (0.16 ms of one xGMI link + 0.17 ms of fix-up against a >= 20 ms scan); CRTFX_SHARD_OVERLAP=1 opts in.
     want_overlap = sharded_iir and (backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1")
-    render = ShardedRender(shard, p, engine, dist=dist, overlap=want_overlap, timing=sharded_iir)
+    render = ShardedRender(shard, p, engine, dist=dist, overlap=want_overlap, timing=sharded_iir, loopback=bool(a.force_dist))
 
     # step s = round s of the frame-sharded render: rank r owns global frames [(s*world + r)*B, ... + B).
     # The per-frame host tables of a step (scanline row gains via np.sin, flicker factors, the ctypes frame records and
@@ -477,7 +508,7 @@ def main():
                 "frames_per_s_own_clock": round(B * a.steps / own_dt, 2) if own_dt else None,
                 "chain_ms_per_frame": round(sum(v[0] * v[1] / v[2] for v in kt_ok.values()), 5) if kt_ok else None,
                 "gpu": telem_first,
-                **({"shard_schedule": render.schedule_report()} if (p > 0.0 and world > 1) else {})}
+                **({"shard_schedule": render.schedule_report()} if sharded_iir else {})}
     per_rank = None
     per_rank_detail = [mine_rec]
     if dist is not None:
@@ -512,13 +543,14 @@ def main():
         "host_tables": {"in_timed_region": not a.tables_outside, "host_seconds_rank0": round(host_first, 4),
                         "note": "per-frame scanline/flicker tables + frame records built and uploaded per step; they overlap the previous step's kernels"},
         "repeat_values": [round(total_frames / d, 2) for d in region_dt[1:]],
-        "dist": {"backend": backend if world > 1 else None, "backend_version": backend_version(backend) if world > 1 else None,
+        "dist": {"backend": backend if use_dist else None, "backend_version": backend_version(backend) if use_dist else None,
+                 **({"forced": True, "note": "--force-dist: the N > 1 code path at world size 1 (a rehearsal of the collectives and the hop, not a scaling result)"} if a.force_dist else {}),
                  "world_size_seen": (dist.get_world_size() if dist is not None else 1), "visible_devices": torch.cuda.device_count(),
                  # how the one-frame persistence hop ran (config 4 at N > 1 only): behind each round's scan ("synchronous") or beside the next one
-                 "hop_schedule": (("overlapped" if render.overlap else "synchronous") if (p > 0.0 and world > 1) else None),
+                 "hop_schedule": (("overlapped" if render.overlap else "synchronous") if sharded_iir else None),
                  "per_rank_frames_per_s": per_rank, "per_rank": per_rank_detail},
     }
-    if p > 0.0 and world > 1:
+    if sharded_iir:
         res["shard_schedule"] = render.schedule_report()
     if rank == 0:
         if kt:

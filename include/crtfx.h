@@ -244,16 +244,26 @@ typedef enum crtfx_option {
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 
-/* Which build of each kernel class the most recent crtfx_apply_static / crtfx_apply / crtfx_process_batch call of this ctx launched LAST, as a
+/* Which build of each kernel class the most recent crtfx_apply_static / crtfx_apply / crtfx_process_batch call of this ctx launched, as a
  * NUL-terminated `key=value;...` string (truncated to n - 1 characters), e.g.
- *   phosphor=k_phosphor_ct<9,u8>;group=2;seg_rows=256;warp=k_warp_lean<f64,none,u8,rows=4,tile=128x16,plain>;warp_frames=2
+ *   phosphor=k_phosphor_ct<9,u8>;group=2;seg_rows=256;group_max=2;warp=k_warp_lean<f64,none,u8,rows=4,tile=128x8,plain>;warp_frames=2
  * keys: phosphor (the fused Gaussian-bloom chain), blur (split bloom passes), half (fast-bloom source), point (pointwise chain), group (frames
- * per grid of the phosphor / pointwise launch), seg_rows (rows per phosphor block), group_max (the planner's frames per grid: the last group of a
- * batch may be shorter), warp, warp_frames.  Every variant of a kernel produces the
- * same bits (tests/test_parity_gpu.py::test_kernel_variants_agree), so a planner regression is invisible to parity tests: this record is what
- * tests/test_plan_gpu.py pins for the BASELINE configs.  (The reference has no counterpart: its "plan" is the fixed numpy / cv2 call sequence
- * of ref:566-698.) */
+ * per grid of the phosphor / pointwise launch), seg_rows (rows per phosphor block), group_max (the planner's frames per grid), warp, warp_frames.
+ * crtfx_process_batch reports its FULL-SIZE launch group — the one with the most frames, the later of equals: a batch that is not a multiple of
+ * the group size ends in one shorter group with a launch shape of its own, which says nothing about the other launches of the call (a batch of
+ * 8192 1080p frames = 1638 groups of 5 frames x 168-row blocks + one of 2 x 64: the plan reads group=5;seg_rows=168).  Every variant of a
+ * kernel produces the same bits (tests/test_parity_gpu.py::test_kernel_variants_agree), so a planner regression is invisible to parity tests:
+ * this record is what tests/test_plan_gpu.py pins for the BASELINE configs.  (The reference has no counterpart: its "plan" is the fixed
+ * numpy / cv2 call sequence of ref:566-698.) */
 int crtfx_last_plan(crtfx_ctx* ctx, char* buf, size_t n);
+
+/* Host-side query (no GPU work, no ctx): the dynamic LDS bytes one block of a column-owner phosphor build asks for at launch —
+ * build = "k_phosphor_ct" (radii 1..15; pix_fmt CRTFX_PIX_U8 or CRTFX_PIX_F16) or "k_phosphor_cc" (radii 1..30).  Their launch shape is
+ * planned for FOUR resident blocks per CU (160 KB of LDS per CU: <= 40 960 bytes per block), and the size is not in the code-object
+ * metadata (`extern __shared__`); tests/test_evidence_tools.py pins it next to the register counts it reads from the library's code
+ * objects.  Returns the byte count, CRTFX_E_UNSUPPORTED for a radius the build does not serve, CRTFX_E_INVALID for a bad argument.
+ * (No reference counterpart.) */
+int crtfx_kernel_lds_bytes(const char* build, int radius, int pix_fmt);
 
 /* -DCRTFX_STAMP diagnostic builds only (tools/phase_profile.py): device buffer the per-wave phase cycle sums are
  * written to.  CRTFX_E_UNSUPPORTED in the product build. */

@@ -84,6 +84,7 @@ SYMBOLS = {
     "crtfx_profile_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "crtfx_profile_read": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "crtfx_last_plan": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "crtfx_kernel_lds_bytes": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "crtfx_host_blur_row": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
 }
 

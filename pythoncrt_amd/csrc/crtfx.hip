@@ -1044,6 +1044,11 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
     };
     auto frame_in = [&](int i) { return static_cast<const uint8_t*>(frames_base) + (size_t)i * frame_stride_bytes; };
     int i = 0, group_no = 0;
+    // crtfx_last_plan describes the call's FULL-SIZE launch group (the one with the most frames; the later of equals): a batch that is not a
+    // multiple of the group size ends in a shorter group with its own launch shape, which is one launch in hundreds (round 5's bench lines
+    // read `group: 2, seg_rows: 64` for a batch of 1638 groups of 5 x 168 rows and one of 2)
+    crtfx_ctx::Plan best = {};
+    auto group_done = [&]() { if (c->plan.group >= best.group) best = c->plan; };
     while (i < n) {
         // ---- grouped path: Gaussian-bloom chain on the register-window kernel, up to group_max frames per launch ----
         int g = 0;
@@ -1112,6 +1117,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 }
                 if (ovl) { HIP_TRY(c, hipEventRecord(c->ev_k2[slot], sw)); c->ev_k2_pending[slot] = true; }
                 HIP_TRY(c, hipGetLastError());
+                group_done();
                 i += g;
                 ++group_no;
                 continue;
@@ -1187,6 +1193,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 }
                 if (warp) launch_warp_group(c, wg, g, false, s, wg.o[0].blend == CRTFX_BLEND_RENDER && g > 1);
                 HIP_TRY(c, hipGetLastError());
+                group_done();
                 i += g;
                 continue;
             }
@@ -1195,8 +1202,10 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
         // ---- general path, one frame ------------------------------------------------------------------------
         int rc = run_chain(c, frame_in(i), frames ? &frames[i] : nullptr, final_out(i), s);
         if (rc) return rc;
+        group_done();
         ++i;
     }
+    if (n > 0) c->plan = best;
 
     if (c->overlap) {      // everything issued on the side stream is ordered before whatever the caller enqueues next
         for (int k = 0; k < 2; ++k)
@@ -1270,6 +1279,19 @@ int crtfx_host_blur_row(const float* row_in, float* row_out, int w, int cn, cons
             row_out[(size_t)x * cn + ch] = s;
         }
     return CRTFX_OK;
+}
+
+int crtfx_kernel_lds_bytes(const char* build, int radius, int pix_fmt) {
+    if (!build || (pix_fmt != CRTFX_PIX_U8 && pix_fmt != CRTFX_PIX_F16)) return CRTFX_E_INVALID;
+    if (!strcmp(build, "k_phosphor_ct")) {
+        if (radius < 1 || radius > (pix_fmt == CRTFX_PIX_F16 ? CT_HALF_MAX_RADIUS : CT_MAX_RADIUS)) return CRTFX_E_UNSUPPORTED;
+        return ct_lds_words(radius, pix_fmt) * 4;
+    }
+    if (!strcmp(build, "k_phosphor_cc")) {
+        if (radius < 1 || radius > RR_MAX_RADIUS) return CRTFX_E_UNSUPPORTED;
+        return cc_lds_words(radius, pix_fmt) * 4;
+    }
+    return CRTFX_E_UNSUPPORTED;
 }
 
 int crtfx_last_plan(crtfx_ctx* c, char* buf, size_t n) {

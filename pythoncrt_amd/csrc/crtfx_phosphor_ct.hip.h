@@ -54,7 +54,10 @@ namespace crtfx {
 // a frame-row window in dwords, at most: (staged pixels + 2 * 8 of aberration) * 3 bytes, + 3 of alignment slack, + 1
 __host__ __device__ constexpr int ct_ndmax(int R) { return ((rr_swp(R) + 16) * 3 + 5) / 4 + 1; }
 // the centre ring: CT_RING_ROWS rows (a power of two >= R + 2 NB for every radius this kernel serves) of TW dwords
-constexpr int CT_RING_ROWS = 32;
+#ifndef CT_RING_ROWS_N
+#define CT_RING_ROWS_N 32  // (overridable only so that tests/test_evidence_tools.py's resource guard can be shown to fail: -DCT_RING_ROWS_N=64 -> 47.9 KB, three blocks per CU)
+#endif
+constexpr int CT_RING_ROWS = CT_RING_ROWS_N;
 // half frames (PIX = 1): no ring.  A sample is two bytes, so a ring row of frame-row windows would be 512 bytes and the ring 16 KB (three blocks
 // per CU).  Instead the A phase parks the window QWORDS (four half samples each) of the trip's eight rows in a one-trip RAW TILE (8 rows of 64
 // qwords = 4 KB) and each consumer thread — which owns one float of the strip row in the V pass and the tail — keeps the raw centre samples of

@@ -99,13 +99,24 @@ class ShardedRender:
     finishes round r-1 (waits for ITS hop — long done — and runs its fix-up), so the state frame travels while the
     next round's scan runs; results come back one call late, `flush()` returns the last.  The overlapped schedule has
     run over gloo only (CPU tests at world 2 / 3 / 8, several ranks on one GPU); callers keep the synchronous run_round
-    as the default over RCCL until it has run on a multi-GPU box (bench.py, cli.main_sharded: CRTFX_SHARD_OVERLAP=1 opts in)."""
+    as the default over RCCL until it has run on a multi-GPU box (bench.py, cli.main_sharded: CRTFX_SHARD_OVERLAP=1 opts in).
 
-    def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None, overlap: bool = False, timing: bool = False):
+    loopback=True (world 1 only): the ring of ONE rank.  Rank 0's successor and predecessor are both rank 0, so the
+    protocol below runs unchanged — zero-state scan, the chunk-final state sent to and received from itself inside one
+    batch_isend_irecv group, p^j fix-up — instead of the sequential-scan shortcut a single rank normally takes.  The
+    frames are those of the in-order render (the chunk before chunk c IS this rank's previous round).  It exists so
+    that the RCCL branch (device-tensor hop, r.wait() ordering the compute stream behind RCCL's stream, both
+    schedules) can run and be checked on a one-GPU box: tests/test_rccl_world1_gpu.py, bench.py --force-dist."""
+
+    def __init__(self, shard: FrameShard, persistence: float, engine, dist=None, group=None, overlap: bool = False, timing: bool = False,
+                 loopback: bool = False):
         self.shard, self.p, self.engine, self.dist, self.group = shard, float(persistence), engine, dist, group
+        if loopback and (shard.world != 1 or dist is None):
+            raise ValueError("loopback=True is the one-rank ring: world 1 with an initialised process group")
+        self.loopback = bool(loopback)
         self.carry_next_round: Optional[torch.Tensor] = None      # rank 0: true final of the previous round's last chunk
         self.parallel_hop = self.p > 0.0 and (self.p ** shard.chunk) < 2.0 ** -24
-        self.overlap = bool(overlap) and self.parallel_hop and shard.world > 1
+        self.overlap = bool(overlap) and self.parallel_hop and (shard.world > 1 or self.loopback)
         self.timing = bool(timing)
         self._worker = None           # staged (gloo + device tensors) overlapped hops run on one worker thread
         # gloo moves one message over ONE TCP pair (~4 GB/s of loopback memcpy): the staged hop of an overlapped schedule
@@ -230,6 +241,10 @@ class ShardedRender:
         """Start the exchange; returns (works, recv buffer or None, staged)."""
         ops, recv = [], None
         d = self.dist
+        if self.loopback and d.get_backend(self.group) == "gloo":
+            # gloo has no pair from a rank to itself: the one-rank ring's hop is a copy there (CPU test of the protocol).  Over RCCL the
+            # same call is a real ncclSend / ncclRecv pair inside one group — the branch the loopback mode exists to run.
+            return [], (send.clone() if (send is not None and src is not None) else None), False
         stage = self._staged(recv_like)
         if dst is not None and send is not None:
             ops.append(d.P2POp(d.isend, send.cpu() if stage else send.contiguous(), dst, self.group))
@@ -332,7 +347,7 @@ class ShardedRender:
         src = (r - 1) % w if (full or r > 0) else None
         rec = {"round": round_index, "c": c, "n": n, "local": local, "out": out, "full": full, "final": final_local,
                "src": src, "dst": dst, "scan": (e0, e1), "posted": None}
-        if not self._staged(final_local):
+        if self.loopback or not self._staged(final_local):
             # RCCL: the transfer is enqueued behind the scan now and runs beside whatever the compute stream does next
             rec["posted"] = self._post(final_local if dst is not None else None, final_local, src, dst)
         else:                               # gloo + device tensors: staged through pinned host memory on a worker thread
@@ -397,7 +412,7 @@ class ShardedRender:
         # frames) gets a fresh slot every round in THIS schedule too — the default over RCCL, and what every p = 0 render runs
         nslots = int(getattr(self.engine, "slots", 1))
         slot_kw = {"slot": round_index % nslots} if nslots >= 2 else {}
-        if w == 1 and p > 0.0 and hasattr(self.engine, "sequential_scan"):
+        if w == 1 and not self.loopback and p > 0.0 and hasattr(self.engine, "sequential_scan"):
             # one rank owns consecutive chunks: carry the state itself (the reference's in-order loop, ref:1081-1105),
             # no zero-state scan and no correction pass
             out, self.carry_next_round = self.engine.sequential_scan(frames, first, None if c == 0 else self.carry_next_round, **slot_kw)
@@ -418,7 +433,7 @@ class ShardedRender:
         import time as _time
         h0 = self._ev(final_local)
         t0 = _time.perf_counter()
-        if w == 1:
+        if w == 1 and not self.loopback:
             carry = self.carry_next_round
             true_final = final_local if carry is None else final_local + (p ** n) * carry
             self.carry_next_round = true_final.clone()
@@ -441,10 +456,13 @@ class ShardedRender:
             if r == 0:
                 carry = None if c == 0 else self.carry_next_round
                 true_final = final_local if carry is None else final_local + (p ** n) * carry
-                if a > 1:
-                    self._send_recv(true_final, final_local, None, 1)
-                if full:
-                    self.carry_next_round = self._send_recv(None, final_local, w - 1, None)
+                if w == 1:                  # loopback: the ring's one hop, rank 0 to itself (send and receive in one group)
+                    self.carry_next_round = self._send_recv(true_final, final_local, 0, 0)
+                else:
+                    if a > 1:
+                        self._send_recv(true_final, final_local, None, 1)
+                    if full:
+                        self.carry_next_round = self._send_recv(None, final_local, w - 1, None)
             else:
                 carry = self._send_recv(None, final_local, r - 1, None)
                 true_final = final_local + (p ** n) * carry

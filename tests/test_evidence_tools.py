@@ -119,6 +119,14 @@ def test_committed_bench_lines_of_the_newest_round_carry_their_counters():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r{newest:02d}_z*_bench.json")))
     assert len(files) >= 5, files                      # the headline + configs 0, 2, 4, 5
     now = bench.source_hash()
+    hashes = {(json.load(open(f))["roofline"].get("traffic_source") or {}).get("source_hash") for f in files}
+    if hashes != {now} and os.environ.get("CRTFX_EVIDENCE_GATE") != "1":
+        # a kernel / header edit since the last evidence round: a release gate, not a unit test (round-5 advisor finding: the CPU suite must not
+        # stay red from the first csrc edit of a round until its last GPU call).  CRTFX_EVIDENCE_GATE=1 (tools/evidence_round.sh sets it for its
+        # closing check) makes this a failure again.
+        import pytest
+        pytest.xfail(f"committed bench lines were measured on sources {sorted(h or 'none' for h in hashes)}, the tree is {now}: "
+                     f"re-run tools/evidence_round.sh (GPU box) and commit profiles/")
     for f in files:
         d = json.load(open(f))
         r = d["roofline"]
@@ -130,3 +138,118 @@ def test_committed_bench_lines_of_the_newest_round_carry_their_counters():
         assert r.get("plan") and d.get("config", {}).get("workload"), os.path.basename(f)
         if r.get("mall_ceiling") is not None:
             assert "this box" in r["mall_ceiling"]["source"], os.path.basename(f)       # measured in the run, never a committed figure
+
+
+# ---- the resources the four-blocks-per-CU design hangs on (round 6) -------------------------------------------------------------------------
+# k_phosphor_ct is planned for FOUR resident 256-thread blocks per CU (plan_grid simulates 4 x 256 block slots): that needs <= 128 VGPRs per
+# lane (512 / 4), no spills (scratch traffic in the trip loop) and <= 40 960 bytes of LDS per block (160 KB / 4).  A compiler bump, a flag or one
+# more live value that pushes a build over either limit costs 12 - 22 % (profiles/r03_ct_ablation.txt, E: three blocks per CU) with every
+# parity test and the plan string unchanged.  The figures are read from the code objects inside the built libcrtfx.so (tools/kernel_resources.py)
+# and from crtfx_kernel_lds_bytes — no GPU.  Shown to guard (profiles/r06_resource_guard.txt): a library built with -DCT_WAVES=5 or
+# -DCT_RING_ROWS_N=64 fails `check_resources`.
+
+CT_PINNED = {                       # (radius, pix): (VGPRs, LDS bytes) of the builds the BASELINE configs land on (tests/test_plan_gpu.py)
+    (9, 0): (110, 39712),           # configs[2] 4K: k_phosphor_ct<9,u8>
+    (9, 1): (118, 35616),           # configs[4] 8K half: k_phosphor_ct<9,half>
+    (4, 0): (94, 38176),            # configs[1], [3] 1080p: k_phosphor_ct<4,u8>
+}
+# the other kernels of the configs' plans: VGPR ceiling = the occupancy step the committed build sits under (256-thread blocks: waves per SIMD =
+# 512 // VGPRs rounded up to 8), static LDS bytes
+OTHER_PINNED = {
+    "crtfx::k_warp_lean<true, 0, 0, 4, false, 2, false, true>": (72, 0),      # configs 2, 3: f64, no blend, u8, 4 rows, plain (67 VGPRs: 7 waves)
+    "crtfx::k_warp_lean<true, 1, 0, 2, false, 1, true, true>": (80, 0),       # config 4: persistence run, 2 rows, plain (76: 6 waves)
+    "crtfx::k_warp_lean<true, 0, 1, 4, false, 2, false, true>": (80, 0),      # config 5: half rows (74: 6 waves)
+    "crtfx::k_point_lean_seq<16821680u, 0, 1>": (128, 8224),                  # the reference CLI's defaults: fast bloom + pixelate, u8, render blend (106; 1024-thread blocks)
+    "crtfx::k_half_group<16821680u, 0>": (32, 0),                             # ... and its half-resolution bloom source (24)
+}
+
+
+def check_resources(lib_path):
+    """Problems (strings) with the register / spill / LDS figures of the library at lib_path; [] = every pinned figure holds."""
+    import ctypes
+    import kernel_resources
+    res = kernel_resources.resources(lib_path)
+    lib = ctypes.CDLL(lib_path)
+    lib.crtfx_kernel_lds_bytes.restype = ctypes.c_int
+    lib.crtfx_kernel_lds_bytes.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    bad = []
+    for pix in (0, 1):
+        for radius in range(1, 16):
+            k = res.get(f"crtfx::k_phosphor_ct<{radius}, {pix}>")
+            if k is None:
+                bad.append(f"k_phosphor_ct<{radius},{pix}> is not in the library")
+                continue
+            lds = lib.crtfx_kernel_lds_bytes(b"k_phosphor_ct", radius, pix)
+            if not (0 < lds <= 40960):
+                bad.append(f"k_phosphor_ct<{radius},{pix}>: {lds} bytes of LDS > 40960 (three blocks per CU)")
+            if k["vgpr_count"] + k["agpr_count"] > 128:
+                bad.append(f"k_phosphor_ct<{radius},{pix}>: {k['vgpr_count']} + {k['agpr_count']} VGPRs > 128 (fewer than four waves per SIMD)")
+            if k["group_segment_fixed_size"] != 0:
+                bad.append(f"k_phosphor_ct<{radius},{pix}>: static LDS {k['group_segment_fixed_size']} on top of the dynamic block")
+            if radius <= 12 and (k["vgpr_spill_count"] or k["sgpr_spill_count"] or k["private_segment_fixed_size"]):
+                bad.append(f"k_phosphor_ct<{radius},{pix}>: spills ({k['vgpr_spill_count']} VGPR, {k['sgpr_spill_count']} SGPR, "
+                           f"{k['private_segment_fixed_size']} bytes of scratch) at a radius that had none")
+            if radius > 12 and k["vgpr_spill_count"] > 24:
+                bad.append(f"k_phosphor_ct<{radius},{pix}>: {k['vgpr_spill_count']} VGPRs spilled (committed: <= 23, profiles/r05_half_sigma.txt)")
+    for (radius, pix), (vg, lds_b) in CT_PINNED.items():
+        k = res.get(f"crtfx::k_phosphor_ct<{radius}, {pix}>")
+        if k is None:
+            continue
+        if k["vgpr_count"] > vg + 6:            # a few registers of compiler noise are fine, a jump towards the 128 limit is a change to look at
+            bad.append(f"k_phosphor_ct<{radius},{pix}>: {k['vgpr_count']} VGPRs, committed {vg}")
+        if lib.crtfx_kernel_lds_bytes(b"k_phosphor_ct", radius, pix) != lds_b:
+            bad.append(f"k_phosphor_ct<{radius},{pix}>: LDS {lib.crtfx_kernel_lds_bytes(b'k_phosphor_ct', radius, pix)} bytes, committed {lds_b}")
+    for name, (vmax, lds_b) in OTHER_PINNED.items():
+        k = res.get(name)
+        if k is None:
+            bad.append(f"{name} is not in the library")
+            continue
+        if k["vgpr_count"] + k["agpr_count"] > vmax:
+            bad.append(f"{name}: {k['vgpr_count']} VGPRs > {vmax} (one occupancy step down)")
+        if k["vgpr_spill_count"] or k["sgpr_spill_count"] or k["private_segment_fixed_size"]:
+            bad.append(f"{name}: spills / scratch ({k['vgpr_spill_count']}, {k['sgpr_spill_count']}, {k['private_segment_fixed_size']} B)")
+        if k["group_segment_fixed_size"] != lds_b:
+            bad.append(f"{name}: static LDS {k['group_segment_fixed_size']} bytes, committed {lds_b}")
+    return bad
+
+
+def test_headline_kernels_keep_their_registers_and_lds():
+    from pythoncrt_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    bad = check_resources(_lib.LIB_PATH)
+    assert not bad, "\n".join(bad)
+
+
+def test_kernel_lds_query_arguments():
+    from pythoncrt_amd import _lib
+    lib = _lib.load()
+    assert lib.crtfx_kernel_lds_bytes(b"k_phosphor_ct", 16, 0) == -3 and lib.crtfx_kernel_lds_bytes(b"k_phosphor_ct", 0, 0) == -3
+    assert lib.crtfx_kernel_lds_bytes(b"k_phosphor_ct", 9, 7) == -1 and lib.crtfx_kernel_lds_bytes(None, 9, 0) == -1
+    assert lib.crtfx_kernel_lds_bytes(b"k_nothing", 9, 0) == -3 and lib.crtfx_kernel_lds_bytes(b"k_phosphor_cc", 20, 0) > 40960
+
+
+def test_pmc_vmem_aggregator_refuses_a_missing_pass(tmp_path):
+    """tools/pmc_vmem_aggregate.py: a pass without a CSV, or a kernel without one of a pass's counters, is an error and NO JSON is written
+    (round 5: the `tc` pass died inside rocprofv3 and the script wrote a JSON without its counters)."""
+    import pmc_vmem_aggregate as agg
+    passes = ["ta|TA_BUSY GRBM", "tc1|TA_STALL"]
+
+    def write(name, rows):
+        d = tmp_path / f"t_{name}" / "host" / "1"
+        d.mkdir(parents=True, exist_ok=True)
+        with open(d / "1_counter_collection.csv", "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for r in rows:
+                f.write(",".join(str(x) for x in r) + "\n")
+
+    write("ta", [('"void crtfx::k_a<1>(int)"', "TA_BUSY", 10), ('"void crtfx::k_a<1>(int)"', "TA_BUSY", 30), ('"void crtfx::k_a<1>(int)"', "GRBM", 5),
+                 ("other_kernel", "TA_BUSY", 99)])
+    assert agg.main(["x", str(tmp_path), "t"] + passes) == 2 and not (tmp_path / "t_vmem.json").exists()          # pass tc1 missing
+    write("tc1", [('"void crtfx::k_b<2>(int)"', "TA_STALL", 7)])
+    assert agg.main(["x", str(tmp_path), "t"] + passes) == 2 and not (tmp_path / "t_vmem.json").exists()          # k_a lacks TA_STALL, k_b the ta pass
+    write("tc1", [('"void crtfx::k_a<1>(int)"', "TA_STALL", 7)])
+    assert agg.main(["x", str(tmp_path), "t"] + passes) == 0
+    import json
+    out = json.load(open(tmp_path / "t_vmem.json"))
+    assert out == {"crtfx::k_a<1>": {"TA_BUSY": 20.0, "GRBM": 5.0, "TA_STALL": 7.0}}

@@ -168,6 +168,49 @@ def test_overlapped_schedule_matches_in_order(tmp_path, world):
     check_cases(tmp_path, cases)
 
 
+def loopback_worker(rank, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    rows = []
+    for overlap in (False, True):
+        for p, chunk, n_frames in LOOPBACK_CASES:
+            frames = clip_frames(n_frames)
+            shard = FrameShard(1, 0, chunk)
+            render = ShardedRender(shard, p, OracleEngine(p), dist=dist, overlap=overlap, loopback=True)
+            outs = {}
+            for r in range(shard.rounds(n_frames)):
+                lo, hi = shard.frame_range(r, n_frames)
+                for rr, o in render.submit_round(torch.from_numpy(np.stack(frames[lo:hi])), r, active=1):
+                    outs[rr] = o.numpy()
+            for rr, o in render.close():
+                outs[rr] = o.numpy()
+            np.save(os.path.join(outdir, f"lb_{int(overlap)}_{len(rows) % len(LOOPBACK_CASES)}.npy"), np.concatenate([outs[k] for k in sorted(outs)]))
+            rows.append((render.overlap, render.parallel_hop))
+    assert rows[:len(LOOPBACK_CASES)] == [(False, ph) for _, ph in rows[len(LOOPBACK_CASES):]]
+    assert [ov for ov, _ in rows[len(LOOPBACK_CASES):]] == [ph for _, ph in rows[len(LOOPBACK_CASES):]]      # overlapped exactly where a round is one parallel hop
+    dist.destroy_process_group()
+
+
+LOOPBACK_CASES = [(0.5, 26, 26 * 3), (0.5, 26, 26 * 2 + 7), (0.5, 3, 10), (0.9, 5, 12), (0.0, 4, 9), (0.6, 4, 4)]
+
+
+def test_loopback_ring_of_one_rank(tmp_path):
+    """ShardedRender(loopback=True): world 1 run as a ring whose one rank is its own neighbour — the mode the RCCL branch is exercised with
+    on a one-GPU box (tests/test_rccl_world1_gpu.py, bench.py --force-dist).  Same frames as the in-order render under both schedules and
+    both hop protocols.  (gloo has no pair from a rank to itself, so the hop is a copy here; over RCCL it is a send / recv pair.)"""
+    mp.spawn(loopback_worker, args=(free_port(), str(tmp_path)), nprocs=1, join=True)
+    for overlap in (0, 1):
+        for k, (p, chunk, n_frames) in enumerate(LOOPBACK_CASES):
+            got = np.load(tmp_path / f"lb_{overlap}_{k}.npy")
+            exp = in_order_render(p, n_frames)
+            d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+            assert got.shape == exp.shape and d.max() <= 1 and (d != 0).mean() < 2e-3, (overlap, k, int(d.max()))
+    with pytest.raises(ValueError):
+        ShardedRender(FrameShard(2, 0, 26), 0.5, None, loopback=True)
+
+
 def test_ring_direction_is_observable():
     """The protocol's peers at world 8 (what a world-2 test cannot see): rank r sends to r+1 and receives from r-1;
     in a partial round the ring is cut after the last active rank and rank 0 receives nothing."""
