@@ -232,6 +232,7 @@ class _MappedInput:
         self._zap_q = queue.Queue()
         self._zap_mode = os.environ.get("CRTFX_IO_DONTNEED", "thread")      # A/B knob: "thread" (default) | "0" (never: left to process exit) | "slice" (on the copy threads, round 4)
         self._zap_thr = None
+        self._zap_err = False
         if self.map is not None and self._zap_mode == "thread" and hasattr(mmap, "MADV_DONTNEED"):
             def zapper():
                 while True:
@@ -239,9 +240,10 @@ class _MappedInput:
                     if job is None:
                         return
                     a0, a1 = job
-                    while a0 < a1:
+                    while a0 < a1 and not self._zap_err:
                         k = min(a1 - a0, 32 << 20)
-                        _madvise(self.base + a0, k, mmap.MADV_DONTNEED)
+                        if _madvise(self.base + a0, k, mmap.MADV_DONTNEED) != 0:
+                            self._zap_err = True      # the first failure ends the drops (they are an optimisation): a raw address is never advised blindly
                         a0 += k
             self._zap_thr = threading.Thread(target=zapper, name="crtfx-zap", daemon=True)
             self._zap_thr.start()
@@ -291,8 +293,8 @@ class _MappedInput:
     def close(self):
         if self._zap_thr is not None:
             self._zap_q.put(None)
-            self._zap_thr.join(timeout=30)
-            self._zap_thr = None
+            self._zap_thr.join()                    # no timeout: the thread advises RAW addresses of this mapping, which must outlive it (a drop of a
+            self._zap_thr = None                    # 400 MB batch takes ~13 ms; the queue holds at most the batches read)
         self.arr = None
         if self.map is not None:
             try:
@@ -661,6 +663,11 @@ class _Writer:
         import threading
         import torch
         self._torch, self.shape, self.frame_bytes = torch, shape, frame_bytes
+        self._os, self._closed = os, False
+        try:
+            self._fd = fout.fileno() if positional else None
+        except (OSError, ValueError, AttributeError):
+            self._fd = None
         self._bufs = [None] * slots
         self._pin_lock = threading.Lock()
         self.free, self.work = queue.Queue(), queue.Queue()
@@ -778,7 +785,19 @@ class _Writer:
                 self.tokens.release()
             self.prep.join(timeout=30)
         if self.rmap is not None:
+            if self.mapped_batches and not self._closed:
+                # the download DMA wrote MAP_SHARED pages of the output file directly: msync + fsync before the windows are unregistered and the
+                # mapping goes, so that the frames' way to the disk does not hang on how the driver marked the pinned pages (INTEGRATION.md,
+                # "--io mapped durability"); on tmpfs both calls return at once
+                try:
+                    self.rmap.map.flush()
+                    if self._fd is not None:
+                        self._os.fsync(self._fd)
+                except (OSError, ValueError) as e:
+                    if self.err is None:
+                        self.err = e
             self.rmap.close()
+        self._closed = True
         if self.err is not None:
             raise self.err
 
@@ -804,6 +823,11 @@ def main_sharded(a, rank: int, world: int) -> int:
     torch.cuda.set_device(dev)
     backend = os.environ.get("CRTFX_DIST_BACKEND", "nccl" if ndev >= world else "gloo")     # gloo: rehearsal of N ranks on fewer GPUs
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:                  # CRTFX_FORCE_DIST=1 without a launcher
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
     dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     rs = settings_from_args(a)
     fps_out = int(a.fps) if a.fps and a.fps > 0 else 24
@@ -827,7 +851,9 @@ def main_sharded(a, rank: int, world: int) -> int:
     down_delay_ms = float(os.environ.get("CRTFX_TEST_DOWNLOAD_DELAY_MS", "0") or 0)
     # three output slots: round r's frames may still be on their way to the host (download stream) while round r + 1 is scanned and —
     # overlapped schedule, results one call late — round r + 2 is enqueued
-    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=3), dist=dist, overlap=overlap)
+    # world 1 arrives here only as CRTFX_FORCE_DIST=1 (main): the one-rank ring — the same protocol with rank 0 as its own neighbour, so that
+    # this function's RCCL branch (eager communicator, object broadcast, the hop between the three streams below) runs on a one-GPU box
+    render = ShardedRender(shard, rs.persistence, GpuShardEngine(pipe, B, slots=3), dist=dist, overlap=overlap, loopback=(world == 1))
     if rank == 0:
         with open(a.output, "wb") as f:
             f.truncate(n_frames * frame_bytes)
@@ -910,10 +936,10 @@ def main_sharded(a, rank: int, world: int) -> int:
 def main(argv=None) -> int:
     a = build_parser().parse_args(argv)
     import os as _os
-    if int(_os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(_os.environ.get("WORLD_SIZE", "1")) > 1 or _os.environ.get("CRTFX_FORCE_DIST") == "1":
         if a.gui or not a.input or a.width <= 0 or a.height <= 0:
             raise SystemExit("pass --input, --width and --height")
-        return main_sharded(a, int(_os.environ.get("RANK", "0")), int(_os.environ["WORLD_SIZE"]))
+        return main_sharded(a, int(_os.environ.get("RANK", "0")), int(_os.environ.get("WORLD_SIZE", "1")))
     if a.gui or not a.input:
         raise SystemExit("the GUI is not part of this path; pass --input (raw rgb24 file or '-')")
     if a.width <= 0 or a.height <= 0:
@@ -941,12 +967,15 @@ def main(argv=None) -> int:
     t0 = time.perf_counter()
     # regular files: positional I/O on a few threads (a pipe / the terminal: the plain sequential calls)
     in_pos = _seekable(fin) and a.input != "-"
-    # the output is opened with read access too (a MAP_SHARED, PROT_WRITE mapping needs O_RDWR).  An existing regular output file behind a
-    # regular input file is NOT truncated at open: it is sized to the clip below, and the pages it already has in the page cache are
-    # overwritten in place (registering them is several times faster than allocating new ones)
+    # the output is opened with read access too (a MAP_SHARED, PROT_WRITE mapping needs O_RDWR).  --io mapped | auto only: an existing regular
+    # output file behind a regular input file is NOT truncated at open — it is sized to the clip below and the pages it already has in the page
+    # cache are overwritten in place (registering them is several times faster than allocating new ones).  The default (--io staged) truncates at
+    # open and the file GROWS as batches are written, so that a render that dies leaves a short file, never a full-length one holding frames of an
+    # earlier render (round-5 advisor finding); the sized paths cut the file back to the frames actually written when the render raises (below).
     if in_pos and out_path != "-" and os.path.exists(out_path) and os.path.samefile(out_path, a.input):
         raise SystemExit("--output is the input file")
-    keep_pages = in_pos and out_path != "-" and os.path.isfile(out_path)
+    presize = in_pos and out_path != "-" and a.io in ("mapped", "auto")
+    keep_pages = presize and os.path.isfile(out_path)
     fout = sys.stdout.buffer if out_path == "-" else open(out_path, "r+b" if keep_pages else "w+b")
     out_pos = fout is not sys.stdout.buffer and _seekable(fout)
     pipe_in, pipe_out = (0 if in_pos else _grow_pipe(fin)), (0 if out_pos else _grow_pipe(fout))      # pipes: the largest buffer the kernel allows
@@ -956,7 +985,8 @@ def main(argv=None) -> int:
     if in_pos and out_pos:
         n_total = os.fstat(fin.fileno()).st_size // frame_bytes
         out_plan = [(k * B * frame_bytes, min(B, n_total - k * B) * frame_bytes) for k in range((n_total + B - 1) // B)] or None
-        os.ftruncate(fout.fileno(), n_total * frame_bytes)
+        if presize and out_pos:
+            os.ftruncate(fout.fileno(), n_total * frame_bytes)
 
     def jobs():                                                     # whole batches until the stream ends (the reader stops at a short read)
         off = 0
@@ -978,73 +1008,96 @@ def main(argv=None) -> int:
     state, index, k, out_off, pend = None, 0, 0, 0, None
     t_get = t_enq = t_slot = t_rel = 0.0
     marks = []
-    while True:
-        tt = time.perf_counter()
-        item = reader.get()
-        t_get += time.perf_counter() - tt
-        if item is None:
-            break
-        i, n, got = item                                            # a trailing partial frame is dropped, as ffmpeg's rawvideo demuxer does
-        tt = time.perf_counter()
-        if n:
-            d = k % NS
-            # upload k on its own stream, once the kernels that last read this device slot (batch k - NS) are done
-            if kernels_done[d] is not None:
-                s_up.wait_event(kernels_done[d])
-            tim = a.staging_report
-            if tim:
-                u0 = torch.cuda.Event(enable_timing=True); u0.record(s_up)
-            reader.upload(i, n, dev_in[d], s_up)              # from the pinned slot, or straight from the registered file mapping
-            up = torch.cuda.Event(enable_timing=tim)
-            up.record(s_up)
-            # kernels k behind the upload, and behind the download that last read this output slot
-            compute.wait_event(up)
-            if down_done[d] is not None:
-                compute.wait_event(down_done[d])
-            if tim:
-                k0 = torch.cuda.Event(enable_timing=True); k0.record(compute)
-            _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
-            kd = torch.cuda.Event(enable_timing=tim)
-            kd.record(compute)
-            kernels_done[d] = kd
-            # download k on the third stream into a free pinned slot; the writer thread takes it from there
+    try:
+        while True:
+            tt = time.perf_counter()
+            item = reader.get()
+            t_get += time.perf_counter() - tt
+            if item is None:
+                break
+            i, n, got = item                                            # a trailing partial frame is dropped, as ffmpeg's rawvideo demuxer does
+            tt = time.perf_counter()
+            if n:
+                d = k % NS
+                # upload k on its own stream, once the kernels that last read this device slot (batch k - NS) are done
+                if kernels_done[d] is not None:
+                    s_up.wait_event(kernels_done[d])
+                tim = a.staging_report
+                if tim:
+                    u0 = torch.cuda.Event(enable_timing=True); u0.record(s_up)
+                reader.upload(i, n, dev_in[d], s_up)              # from the pinned slot, or straight from the registered file mapping
+                up = torch.cuda.Event(enable_timing=tim)
+                up.record(s_up)
+                # kernels k behind the upload, and behind the download that last read this output slot
+                compute.wait_event(up)
+                if down_done[d] is not None:
+                    compute.wait_event(down_done[d])
+                if tim:
+                    k0 = torch.cuda.Event(enable_timing=True); k0.record(compute)
+                _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
+                kd = torch.cuda.Event(enable_timing=tim)
+                kd.record(compute)
+                kernels_done[d] = kd
+                # download k on the third stream into a free pinned slot; the writer thread takes it from there
+                t_enq += time.perf_counter() - tt
+                tt = time.perf_counter()
+                j = writer.slot()
+                t_slot += time.perf_counter() - tt
+                tt = time.perf_counter()
+                s_down.wait_event(kd)
+                if tim:
+                    d0 = torch.cuda.Event(enable_timing=True); d0.record(s_down)
+                writer.download(j, n, dev_out[d], s_down)         # into the pinned slot, or straight into the registered output mapping
+                dn = torch.cuda.Event(enable_timing=tim)
+                dn.record(s_down)
+                down_done[d] = dn
+                if tim:
+                    marks.append((u0, up, k0, kd, d0, dn, n))
+                writer.put(j, n, dn, out_off if out_pos else None)
+                out_off += n * frame_bytes
+            # a pinned input slot goes back to the reader once its upload has completed: the PREVIOUS batch's is waited for here (long done),
+            # so this thread never sits on the upload it has just enqueued
             t_enq += time.perf_counter() - tt
             tt = time.perf_counter()
-            j = writer.slot()
-            t_slot += time.perf_counter() - tt
-            tt = time.perf_counter()
-            s_down.wait_event(kd)
-            if tim:
-                d0 = torch.cuda.Event(enable_timing=True); d0.record(s_down)
-            writer.download(j, n, dev_out[d], s_down)         # into the pinned slot, or straight into the registered output mapping
-            dn = torch.cuda.Event(enable_timing=tim)
-            dn.record(s_down)
-            down_done[d] = dn
-            if tim:
-                marks.append((u0, up, k0, kd, d0, dn, n))
-            writer.put(j, n, dn, out_off if out_pos else None)
-            out_off += n * frame_bytes
-        # a pinned input slot goes back to the reader once its upload has completed: the PREVIOUS batch's is waited for here (long done),
-        # so this thread never sits on the upload it has just enqueued
-        t_enq += time.perf_counter() - tt
-        tt = time.perf_counter()
+            if pend is not None:
+                pend[0].synchronize()
+                reader.release(pend[1])
+                pend = None
+            t_rel += time.perf_counter() - tt
+            if n:
+                pend = (up, i)
+            else:
+                reader.release(i)
+            index += n
+            k += 1
+            if got < B * frame_bytes:
+                break
         if pend is not None:
             pend[0].synchronize()
             reader.release(pend[1])
-            pend = None
-        t_rel += time.perf_counter() - tt
-        if n:
-            pend = (up, i)
-        else:
-            reader.release(i)
-        index += n
-        k += 1
-        if got < B * frame_bytes:
-            break
-    if pend is not None:
-        pend[0].synchronize()
-        reader.release(pend[1])
-    writer.close()
+        writer.close()
+    except BaseException:
+        # the render died (a read / write / HIP error, KeyboardInterrupt): everything queued on the GPU is drained, the writer is stopped, and a
+        # regular output file is cut back to the frames that were actually written — in order, so a prefix — instead of keeping its planned length
+        try:
+            torch.cuda.synchronize(dev)
+        except Exception:       # noqa: BLE001
+            pass
+        try:
+            writer.close()
+        except BaseException:   # noqa: BLE001 - the first error is the one to report
+            pass
+        try:
+            reader.close()
+        except BaseException:   # noqa: BLE001
+            pass
+        if out_pos:
+            try:
+                fout.flush()
+                os.ftruncate(fout.fileno(), min(int(writer.frames), index) * frame_bytes)
+            except OSError:
+                pass
+        raise
     t_pipe = time.perf_counter() - t_pipe
     reader.close()
     fout.flush()

@@ -59,7 +59,11 @@ def process_frames(frame_iter: Iterable[np.ndarray], write_frame: Callable[[np.n
     Effect keywords: the names, meaning and defaults of process_video / the CLI (ref:864-911, :1155-1206); the caller applies the clamps of
     ref:1225-1266 as the reference's `main` does (`pythoncrt_amd.cli.settings_from_args` restates them).  Returns the number of frames written.
     The array passed to `write_frame` is a view of a staging buffer that is reused two batches later: consume it inside the call (the
-    reference's `FFMPEG_VideoWriter.write_frame` writes it to the encoder's pipe at once)."""
+    reference's `FFMPEG_VideoWriter.write_frame` writes it to the encoder's pipe at once).
+    `progress_cb(fraction)` is called after every written frame with min(1, written / total_frames) (ref:1104-1105; the reference always knows
+    its total, ref:1029).  With `total_frames=None` no fraction can be formed: the callback is then called ONCE, with 1.0, after the last frame.
+    If `frame_iter` or `write_frame` raises, the GPU work already queued is drained (device synchronize) before the exception leaves this
+    function, so that the staging buffers are not freed under a running copy."""
     import os
     import torch
     from .pipeline import FramePipeline, RenderSettings
@@ -122,51 +126,60 @@ def process_frames(frame_iter: Iterable[np.ndarray], write_frame: Callable[[np.n
             if progress_cb is not None and total:
                 progress_cb(min(1.0, written / float(total)))                   # ref:1104-1105
 
-    it = iter(frame_iter)
-    done = False
-    while not done:
-        d = k % NS
-        if up_done[d] is not None:
-            up_done[d].synchronize()             # the upload that read this pinned slot two batches ago (long done)
-        n = 0
-        while n < B:
-            try:
-                frame = next(it)
-            except StopIteration:
-                done = True
-                break
-            np.copyto(np_in[d][n], fit(frame), casting="unsafe")
-            n += 1
-        if n:
-            if kernels_done[d] is not None:
-                s_up.wait_event(kernels_done[d])
-            with torch.cuda.stream(s_up):
-                dev_in[d][:n].copy_(pin_in[d][:n], non_blocking=True)
-                up = torch.cuda.Event()
-                up.record(s_up)
-            up_done[d] = up
-            compute.wait_event(up)
-            if down_done[d] is not None:
-                compute.wait_event(down_done[d])
-            _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
-            kd = torch.cuda.Event()
-            kd.record(compute)
-            kernels_done[d] = kd
-            # pin_out[d] was drained one iteration ago (drain below runs before the next batch is enqueued into the same slot)
-            s_down.wait_event(kd)
-            with torch.cuda.stream(s_down):
-                pin_out[d][:n].copy_(dev_out[d][:n], non_blocking=True)
-                dn = torch.cuda.Event()
-                dn.record(s_down)
-            down_done[d] = dn
-            index += n
-        # the PREVIOUS batch's frames go to the writer while this batch is on the GPU
+    try:
+        it = iter(frame_iter)
+        done = False
+        while not done:
+            d = k % NS
+            if up_done[d] is not None:
+                up_done[d].synchronize()             # the upload that read this pinned slot two batches ago (long done)
+            n = 0
+            while n < B:
+                try:
+                    frame = next(it)
+                except StopIteration:
+                    done = True
+                    break
+                np.copyto(np_in[d][n], fit(frame), casting="unsafe")
+                n += 1
+            if n:
+                if kernels_done[d] is not None:
+                    s_up.wait_event(kernels_done[d])
+                with torch.cuda.stream(s_up):
+                    dev_in[d][:n].copy_(pin_in[d][:n], non_blocking=True)
+                    up = torch.cuda.Event()
+                    up.record(s_up)
+                up_done[d] = up
+                compute.wait_event(up)
+                if down_done[d] is not None:
+                    compute.wait_event(down_done[d])
+                _, state = pipe.run(dev_in[d][:n], first_index=index, state=state, out=dev_out[d][:n])
+                kd = torch.cuda.Event()
+                kd.record(compute)
+                kernels_done[d] = kd
+                # pin_out[d] was drained one iteration ago (drain below runs before the next batch is enqueued into the same slot)
+                s_down.wait_event(kd)
+                with torch.cuda.stream(s_down):
+                    pin_out[d][:n].copy_(dev_out[d][:n], non_blocking=True)
+                    dn = torch.cuda.Event()
+                    dn.record(s_down)
+                down_done[d] = dn
+                index += n
+            # the PREVIOUS batch's frames go to the writer while this batch is on the GPU
+            if pending is not None:
+                drain(pending)
+                pending = None
+            if n:
+                pending = (d, n, dn)
+            k += 1
         if pending is not None:
             drain(pending)
-            pending = None
-        if n:
-            pending = (d, n, dn)
-        k += 1
-    if pending is not None:
-        drain(pending)
+    except BaseException:
+        try:
+            torch.cuda.synchronize(dev)          # uploads / kernels / downloads still in flight reference the buffers above
+        except Exception:       # noqa: BLE001 - the caller's exception is the one to report
+            pass
+        raise
+    if progress_cb is not None and not total:
+        progress_cb(1.0)
     return written

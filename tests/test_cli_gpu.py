@@ -379,3 +379,59 @@ def test_process_frames_is_the_render_loop(pc, case):
     # a keyword that is neither an effect nor one of process_video's I/O keywords is refused
     with pytest.raises(TypeError):
         pc.process_frames(iter(feed), lambda a: None, w, h, fps, n, scanlines=0.5)
+
+
+@pytest.mark.parametrize("io", ["staged", "mapped"])
+def test_cli_failed_render_leaves_no_stale_frames(pc, tmp_path, monkeypatch, io):
+    """Round-5 advisor finding: a file-to-file render over an EXISTING longer output that dies midway must not leave a full-length file whose
+    tail holds frames of the earlier render.  The third batch's launch is made to raise; afterwards the file holds exactly the frames that were
+    written (a prefix of the correct render, whole frames), for the growing staged output and for the pre-sized mapped one."""
+    from pythoncrt_amd import cli
+    from pythoncrt_amd.pipeline import FramePipeline
+    n, h, w, batch = 14, 72, 128, 3
+    frames = clip(n, h, w, 41)
+    fb = h * w * 3
+    src, dst = tmp_path / "in.rgb", tmp_path / "out.rgb"
+    src.write_bytes(frames.tobytes())
+    flags = ["--input", str(src), "--output", str(dst), "--width", str(w), "--height", str(h), "--fps", "30", "--batch", str(batch), "--noise-seed", "3",
+             "--io", io]
+    assert cli.main(flags) == 0
+    good = dst.read_bytes()
+    assert len(good) == n * fb
+    dst.write_bytes(b"\xaa" * ((n + 6) * fb))                  # an earlier, longer render
+    real, calls = FramePipeline.run, [0]
+
+    def run(self, *a, **k):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise RuntimeError("injected failure in batch 3")
+        return real(self, *a, **k)
+    monkeypatch.setattr(FramePipeline, "run", run)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        cli.main(flags)
+    monkeypatch.undo()
+    left = dst.read_bytes()
+    assert len(left) % fb == 0 and len(left) <= 2 * batch * fb, (io, len(left) // fb)
+    assert left == good[:len(left)]                            # whole frames of THIS render; nothing of the 0xAA file survives
+    assert cli.main(flags) == 0 and dst.read_bytes() == good   # and the next render is unaffected
+
+
+def test_process_frames_unknown_total_and_failing_writer(pc):
+    """process_frames with total_frames=None: no fraction can be formed, so progress_cb fires once, with 1.0, after the last frame; a write_frame
+    that raises ends the call with that exception after the queued GPU work has been drained (the next call on the same device works)."""
+    n, h, w = 9, 72, 128
+    frames = list(clip(n, h, w, 13))
+    got, prog = [], []
+    assert pc.process_frames(iter(frames), lambda a: got.append(np.array(a)), w, h, 25, None, batch=4, noise_seed=5, progress_cb=prog.append) == n
+    assert prog == [1.0] and len(got) == n
+
+    def bad(a):
+        if len(seen) == 5:
+            raise OSError("encoder pipe closed")
+        seen.append(1)
+    seen = []
+    with pytest.raises(OSError, match="encoder pipe closed"):
+        pc.process_frames(iter(frames), bad, w, h, 25, n, batch=4, noise_seed=5)
+    again = []
+    assert pc.process_frames(iter(frames), lambda a: again.append(np.array(a)), w, h, 25, n, batch=4, noise_seed=5) == n
+    assert np.array_equal(np.stack(again), np.stack(got))

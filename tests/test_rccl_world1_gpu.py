@@ -76,3 +76,34 @@ def test_bench_force_dist_runs_the_n_gt_1_path_over_rccl(config, batch):
         assert sr["parallel_hop"] and sr["rounds"] >= 3 and sr["fixup_frames"] == 26 and sr["hop_stall_us"] >= 0
     else:
         assert d["hop_schedule"] is None
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_sharded_cli_over_rccl_at_world_1(tmp_path, overlap):
+    """pythoncrt_amd.cli's sharded main (cli.py: eager RCCL communicator, broadcast_object_list of the grain seed, barriers, the hop between
+    its upload / compute / download streams) as the one-rank ring (CRTFX_FORCE_DIST=1), both hop schedules, every download held back by 30 ms
+    of GPU time: the file must hold the plain single-process render's frames (<= 1 LSB with the p^j carry correction, ragged last chunk)."""
+    import numpy as np
+    h, w, n_frames = 270, 480, 26 * 3 + 5
+    rng = np.random.default_rng(23)
+    frames = rng.integers(0, 256, (n_frames, h, w, 3), dtype=np.uint8)
+    src = tmp_path / "in.rgb"
+    src.write_bytes(frames.tobytes())
+    flags = ["--width", str(w), "--height", str(h), "--fps", "30", "--batch", "26", "--noise-seed", "7", "--persistence", "0.5",
+             "--no-fast-bloom", "--bloom-sigma", "1.2", "--warp-strength", "0.15", "--pixel-size", "1"]
+    env = _env()
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    one, two = tmp_path / "one.rgb", tmp_path / "two.rgb"
+    r = subprocess.run([sys.executable, "-m", "pythoncrt_amd.cli", "--input", str(src), "--output", str(one)] + flags,
+                       env={k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env.update(CRTFX_FORCE_DIST="1", CRTFX_SHARD_OVERLAP=overlap, CRTFX_TEST_DOWNLOAD_DELAY_MS="30")
+    r = subprocess.run([sys.executable, "-m", "pythoncrt_amd.cli", "--input", str(src), "--output", str(two)] + flags,
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"rank 0: {n_frames} of {n_frames} frames" in r.stderr
+    a = np.frombuffer(one.read_bytes(), dtype=np.uint8)
+    b = np.frombuffer(two.read_bytes(), dtype=np.uint8)
+    assert a.size == b.size == frames.size
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (int(d.max()), float((d != 0).mean()))
