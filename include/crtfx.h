@@ -236,11 +236,14 @@ int crtfx_warp_map(crtfx_ctx* ctx, int32_t* ix_dev, int32_t* iy_dev, int32_t* fx
  *   SPLIT_FROM           Gaussian-bloom radii >= this run the split path (blur kernels of any radius + the pointwise chain)
  *                        instead of a fused build; default 31 (one fused build per radius up to 30), 0 = every radius
  *   SPLIT_SRC_PLANE      the split path writes the bloom source as a plane first instead of grading while it stages (A/B)
- *   DEBUG_PLAN           print the planned launch shape to stderr */
+ *   DEBUG_PLAN           print the planned launch shape to stderr
+ *   NO_FUSED_HALF        the fast-bloom render chain as two launches (k_half_group writes the half-resolution bloom source, k_point_lean_seq reads
+ *                        it) instead of k_point_fused_seq, which forms the source in LDS (tests, A/B) */
 typedef enum crtfx_option {
     CRTFX_OPT_FORCE_GENERIC = 1, CRTFX_OPT_FORCE_RUNTIME_FLAGS = 2, CRTFX_OPT_NO_CC = 3, CRTFX_OPT_GROUP = 4, CRTFX_OPT_SEG_ROWS = 5,
     CRTFX_OPT_WARP_ROWS = 6, CRTFX_OPT_POINT_TILES = 7, CRTFX_OPT_OVERLAP = 8, CRTFX_OPT_DEBUG_PLAN = 9, CRTFX_OPT_FORCE_CC = 10,
-    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12, CRTFX_OPT_NO_CT = 13, CRTFX_OPT_NO_PLAIN_WARP = 14, CRTFX_OPT_BAND_MB = 15
+    CRTFX_OPT_SPLIT_FROM = 11, CRTFX_OPT_SPLIT_SRC_PLANE = 12, CRTFX_OPT_NO_CT = 13, CRTFX_OPT_NO_PLAIN_WARP = 14, CRTFX_OPT_BAND_MB = 15,
+    CRTFX_OPT_NO_FUSED_HALF = 16
 } crtfx_option;
 int crtfx_set_option(crtfx_ctx* ctx, int option, int value);
 

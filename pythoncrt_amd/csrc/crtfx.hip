@@ -69,6 +69,7 @@ struct crtfx_ctx {
     bool no_cc = false;              // CRTFX_OPT_NO_CC: pre-warp launches stay on k_phosphor_rr instead of k_phosphor_cc (tests, A/B)
     int band_mb = 0;                 // CRTFX_OPT_BAND_MB: > 0 = frames whose pre-warp image exceeds that many MiB run band by band (224 keeps a band under the Infinity Cache; tests band small frames with 1); 0 / -1 = whole frames (the default: no gain measured at 8K)
     bool no_plain_warp = false;      // CRTFX_OPT_NO_PLAIN_WARP: k_warp_lean's branch-free build off (tests, A/B)
+    bool no_fused_half = false;      // CRTFX_OPT_NO_FUSED_HALF: the fast-bloom render chain on k_half_group + k_point_lean_seq instead of k_point_fused_seq (tests, A/B)
     bool no_ct = false;              // CRTFX_OPT_NO_CT: ... on k_phosphor_cc instead of k_phosphor_ct (tests, A/B)
     int opt_group = 0, opt_seg_rows = 0;   // CRTFX_OPT_GROUP / CRTFX_OPT_SEG_ROWS: override the launch-shape planner (0 = planner)
     // crtfx_last_plan: which build each kernel class of the most recent apply / process_batch call landed on (every variant of a kernel is
@@ -1157,7 +1158,11 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = gates == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                if (fastb) {
+                const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
+                // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
+                // dx / dy tap tables), a block of >= 4 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tile)
+                const bool fused = lean && fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4;
+                if (fastb && !fused) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
                     ProfEv ph(c, 2, g);
                     plan_note(c->plan.half, "k_half_group<%s,%s>", lean ? sf_name(gates) : "runtime", lean ? pix_name(c->pix_fmt) : "any");
@@ -1165,10 +1170,9 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                     else if (pixelate) { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                     else { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                 }
-                const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 ProfEv pe(c, 0, g);
                 c->plan.group = g;
-                if (lean) plan_note(c->plan.point, "k_point_lean_seq<%s,%s,%s>", sf_name(gates), pix_name(c->pix_fmt), blend_name(kg.o[0].blend == CRTFX_BLEND_RENDER ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE));
+                if (lean) plan_note(c->plan.point, "%s<%s,%s,%s>", fused ? "k_point_fused_seq" : "k_point_lean_seq", sf_name(gates), pix_name(c->pix_fmt), blend_name(kg.o[0].blend == CRTFX_BLEND_RENDER ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE));
                 else plan_note(c->plan.point, "k_point_sel_seq<%s,%s>", pix_name(c->pix_fmt), (!(fl & CRTFX_F_PIXELATE) && !fastb) ? "one-round" : "two-round");
                 if (lean) {
                     dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
@@ -1177,8 +1181,18 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_lean_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } \
                         else { CRTFX_LAUNCH((k_point_lean_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }                      \
                     } while (0)
-                    if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
+#define CRTFX_FSEQ(SFV, PIXV)                                                                                                                            \
+                    do {                                                                                                                                     \
+                        if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } \
+                        else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
+                    } while (0)
+                    if (fused) {
+                        if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
+                        else { if (f16) CRTFX_FSEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST, CRTFX_PIX_U8); }
+                    }
+                    else if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
                     else { if (f16) CRTFX_SEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST, CRTFX_PIX_U8); }
+#undef CRTFX_FSEQ
 #undef CRTFX_SEQ
                 } else {
                     dim3 gp((c->W + TW - 1) / TW, (c->H + waves - 1) / waves);
@@ -1328,6 +1342,7 @@ int crtfx_set_option(crtfx_ctx* c, int option, int value) {
     case CRTFX_OPT_FORCE_RUNTIME_FLAGS: c->force_runtime_flags = value != 0; break;
     case CRTFX_OPT_NO_CC: c->no_cc = value != 0; break;
     case CRTFX_OPT_NO_CT: c->no_ct = value != 0; break;
+    case CRTFX_OPT_NO_FUSED_HALF: c->no_fused_half = value != 0; break;
     case CRTFX_OPT_NO_PLAIN_WARP: c->no_plain_warp = value != 0; break;
     case CRTFX_OPT_BAND_MB: if (value < -1 || value > 4096) return fail(c, CRTFX_E_INVALID, "band_mb %d outside -1..4096", value); c->band_mb = value; break;
     case CRTFX_OPT_FORCE_CC: c->force_cc = value != 0; break;

@@ -557,6 +557,175 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
         }
     }
 }
+
+// k_point_fused_seq — k_point_lean_seq with the fast-bloom source formed INSIDE the kernel (round 6): no k_half_group launch in front of it, no
+// quarter-size plane in memory, the frame fetched once.  (ref:605-607: ds = cv2.resize(src, (W//2, H//2)); blur = cv2.resize(ds, (W, H)).)
+// A block owns a 64 x (ROWS * waves)-pixel tile.  The bilinear 2x upsample of its pixels reads half-resolution columns x0/2 - 1 .. x0/2 + 32 and rows
+// y0/2 - 1 .. y0/2 + waves * ROWS / 2: a (34 x (waves + 2))-entry tile of ds.  Per frame, the block's first threads form one entry each — the 2 x 2 mean
+// of the graded, thresholded source pixels, half_body's arithmetic in half_body's order (with --pixel-size 2, the reference CLI's default, the four
+// samples of a cell are one pixel: fetched and graded once) — into one of TWO LDS tiles (float4 per entry), one barrier per frame:
+//     A(0) | barrier | A(1), B(0) | barrier | A(2), B(1) | ...        A(j): entries of frame j -> tile j & 1;  B(j): the thread's pixels of frame j
+// (A(j + 1) overwrites the tile B(j - 1) read: every thread finished B(j - 1) before it arrived at the barrier in front of B(j).)  Each thread then
+// takes its four taps from LDS instead of from the plane.  Exact 2x decimation only (W and H even: the host checks); same bits as the two-kernel path.
+constexpr int FUSED_TWH = TW / 2 + 2;                       // 34 half-resolution columns per 64-pixel tile
+constexpr int FUSED_MAX_ENT = FUSED_TWH * (16 * CRTFX_POINT_ROWS / 2 + 2);      // 16 waves: 34 x 18 = 612 entries
+template <uint32_t SF, int PIX, int BLENDM>
+__global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G, int nseq) {
+    static_assert((SF & CRTFX_F_BLOOM_FAST) != 0 && CRTFX_POINT_ROWS == 2, "the fused build is the fast-bloom chain, two rows per thread");
+    __shared__ float lut[2 * LUT_STRIDE];
+    __shared__ float4 dst[2][FUSED_MAX_ENT];
+    constexpr int ROWS = CRTFX_POINT_ROWS;
+    KParams P = Pin;
+    P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    if constexpr ((SF & CRTFX_F_TRIAD) && (SF & CRTFX_F_TRIAD_LUT)) {
+        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    }
+    const int lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int waves = blockDim.x >> 6;
+    const int y0 = blockIdx.y * (waves * ROWS);
+    const int ybase = y0 + (threadIdx.x >> 6);     // (a wave whose rows all lie below the frame stays: it takes part in the barriers and stores nothing)
+    const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
+    using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
+    // ---- the entry of the half-resolution tile this thread forms (frame-invariant addressing) ----
+    const int i0 = (x0 >> 1) - 1, j0 = (y0 >> 1) - 1;
+    const int thh = (waves * ROWS) / 2 + 2;
+    const int nent = FUSED_TWH * thh;
+    const bool maker = (int)threadIdx.x < nent;
+    uint32_t ea[6] = {0, 0, 0, 0, 0, 0};           // element offsets inside a row: R, G, B of the cell's left pixel, then of its right pixel
+    uint32_t erow0 = 0, erow1 = 0;                 // element offsets of the cell's two rows
+    bool same_x = false, same_y = false;
+    if (maker) {
+        const int ii = (int)threadIdx.x % FUSED_TWH, jj = (int)threadIdx.x / FUSED_TWH;
+        const int i = min(max(i0 + ii, 0), P.hw - 1), j = min(max(j0 + jj, 0), P.hh - 1);
+        int mx0 = 2 * i, mx1 = 2 * i + 1, my0 = 2 * j, my1 = 2 * j + 1;
+        if constexpr ((SF & CRTFX_F_PIXELATE) != 0) {
+            mx0 = P.xmap[mx0]; mx1 = P.xmap[mx1]; my0 = P.ymap[my0]; my1 = P.ymap[my1];
+            same_x = mx1 == mx0; same_y = my1 == my0;       // pixel size 2: all four samples of the cell are one pixel
+        }
+        erow0 = (uint32_t)my0 * (uint32_t)P.W * 3u; erow1 = (uint32_t)my1 * (uint32_t)P.W * 3u;
+        int xr0 = mx0, xb0 = mx0, xr1 = mx1, xb1 = mx1;
+        if (P.ab != 0) { xr0 = wrap(mx0 - P.ab, P.W); xb0 = wrap(mx0 + P.ab, P.W); xr1 = wrap(mx1 - P.ab, P.W); xb1 = wrap(mx1 + P.ab, P.W); }      // ref:573-575
+        ea[0] = (uint32_t)xr0 * 3u; ea[1] = (uint32_t)mx0 * 3u + 1u; ea[2] = (uint32_t)xb0 * 3u + 2u;
+        ea[3] = (uint32_t)xr1 * 3u; ea[4] = (uint32_t)mx1 * 3u + 1u; ea[5] = (uint32_t)xb1 * 3u + 2u;
+    }
+    // a1..a4 of one source pixel (= fetch_graded_mapped without an overlay: the lean build has none) and its bloom source (ref:601-604)
+    auto src_px = [&](const KFrame& F, uint32_t row, uint32_t er_, uint32_t eg_, uint32_t eb_, float (&v)[3]) {
+        const RawRGB raw = load_raw(PIX, F.in, row + er_, row + eg_, row + eb_);
+        if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { v[0] = P.grade_lut[raw.r]; v[1] = P.grade_lut[256 + raw.g]; v[2] = P.grade_lut[512 + raw.b]; }
+        else { v[0] = norm_px(PIX, raw.r); v[1] = norm_px(PIX, raw.g); v[2] = norm_px(PIX, raw.b); grade(P, v[0], v[1], v[2]); }
+    };
+    auto make_entry = [&](int jf) {
+        const KFrame F = G.f[jf];
+        float a[3], b[3], c[3], d[3];
+        src_px(F, erow0, ea[0], ea[1], ea[2], a);
+        if (same_x) { b[0] = a[0]; b[1] = a[1]; b[2] = a[2]; } else src_px(F, erow0, ea[3], ea[4], ea[5], b);
+        if (same_y) { c[0] = a[0]; c[1] = a[1]; c[2] = a[2]; } else src_px(F, erow1, ea[0], ea[1], ea[2], c);
+        if (same_x) { d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
+        else if (same_y) { d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; }
+        else src_px(F, erow1, ea[3], ea[4], ea[5], d);
+        float o[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;      // = half_body, mean4
+        dst[jf & 1][threadIdx.x] = float4{o[0], o[1], o[2], 0.0f};
+    };
+    // ---- the thread's own pixels (frame-invariant part: k_point_lean_seq's) ----
+    int yr[ROWS];
+    uint32_t t00[ROWS], t01[ROWS], t10[ROWS], t11[ROWS];      // entry indices of the four taps inside the LDS tile
+    uint32_t er[ROWS], eg[ROWS], eb[ROWS];
+    float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
+    F3 st[ROWS];
+    PixMasks M0[ROWS];
+    const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
+#pragma unroll
+    for (int k = 0; k < ROWS; ++k) {
+        const int y = yr[k] = min(ybase + k * waves, P.H - 1);     // a row past the bottom redoes the last one; its stores are skipped
+        {
+            KFrame F0 = G.f[0];
+            F0.scan_plane = nullptr;
+            M0[k] = load_masks(P, F0, y, x);
+        }
+        {
+            const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
+            const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
+            a1[k] = P.ux_a[x]; a0[k] = 1.0f - a1[k]; b1[k] = P.uy_a[y]; b0[k] = 1.0f - b1[k];
+            // tile coordinates; the clamps only ever bind for rows below the frame's last block row (their pixels are not stored)
+            const int lx = min(max(sx - i0, 0), FUSED_TWH - 1), lx1 = min(max(sx1 - i0, 0), FUSED_TWH - 1);
+            const int ly = min(max(sy - j0, 0), thh - 1), ly1 = min(max(sy1 - j0, 0), thh - 1);
+            t00[k] = (uint32_t)(ly * FUSED_TWH + lx); t01[k] = (uint32_t)(ly * FUSED_TWH + lx1);
+            t10[k] = (uint32_t)(ly1 * FUSED_TWH + lx); t11[k] = (uint32_t)(ly1 * FUSED_TWH + lx1);
+        }
+        {   // = fetch_raw's addressing (ref:573-583), frame-invariant
+            int xs = x, ys = y;
+            if constexpr ((SF & CRTFX_F_PIXELATE) != 0) { xs = P.xmap[x]; ys = P.ymap[y]; }
+            const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
+            int xr = xs, xb = xs;
+            if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }
+            er[k] = row + (uint32_t)xr * 3u; eg[k] = row + (uint32_t)xs * 3u + 1u; eb[k] = row + (uint32_t)xb * 3u + 2u;
+        }
+        if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
+    }
+    if (maker) make_entry(0);
+    for (int jf = 0; jf < nseq; ++jf) {
+        __syncthreads();                           // tile jf & 1 (and, the first time, the LUTs) visible; every thread is done with tile (jf + 1) & 1
+        if (maker && jf + 1 < nseq) make_entry(jf + 1);
+        KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
+        F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+        KOut O = G.o[jf];
+        O.pix = PIX;
+        const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
+        const float4* __restrict__ tile = dst[jf & 1];
+        T v[ROWS][3];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const int y = yr[k];
+            PixMasks M = M0[k];
+            if constexpr ((SF & CRTFX_F_SCANLINES) != 0) M.sl = F.scan_row[y];
+            float r, g, b;
+            {   // = fetch_graded (no overlay in the lean build)
+                const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
+                if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+                else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+            }
+            {
+                const float4 p00 = tile[t00[k]], p01 = tile[t01[k]], p10 = tile[t10[k]], p11 = tile[t11[k]];
+                const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
+                const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
+                const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
+                r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+            }
+            tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
+        }
+        const T p = (T)O.p, q = (T)O.q;
+        if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k)
+                if (ybase + k * waves < P.H)
+                    *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            if (ybase + k * waves < P.H) {           // wave-uniform
+                const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
+                float f0, f1, f2;
+                if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
+                    f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
+                    f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
+                    f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
+                    st[k] = F3{f0, f1, f2};
+                } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
+                if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
+                if (O.out_u8) {
+                    PackedPix pk;
+                    if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+                    else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
+                    store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+                }
+            }
+        }
+    }
+}
 #endif  // CRTFX_MAIN_TU
 
 }  // namespace crtfx

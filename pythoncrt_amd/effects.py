@@ -257,7 +257,8 @@ def _fresh_seed() -> int:
 # {"FORCE_GENERIC": 1}.  Empty in the product path; nothing reads the environment.
 DEBUG_OPTIONS = {}
 _OPTION_IDS = {"FORCE_GENERIC": 1, "FORCE_RUNTIME_FLAGS": 2, "NO_CC": 3, "GROUP": 4, "SEG_ROWS": 5, "WARP_ROWS": 6, "POINT_TILES": 7,
-               "OVERLAP": 8, "DEBUG_PLAN": 9, "FORCE_CC": 10, "SPLIT_FROM": 11, "SPLIT_SRC_PLANE": 12, "NO_CT": 13, "NO_PLAIN_WARP": 14, "BAND_MB": 15}
+               "OVERLAP": 8, "DEBUG_PLAN": 9, "FORCE_CC": 10, "SPLIT_FROM": 11, "SPLIT_SRC_PLANE": 12, "NO_CT": 13, "NO_PLAIN_WARP": 14, "BAND_MB": 15,
+               "NO_FUSED_HALF": 16}
 
 
 class Engine:

@@ -501,6 +501,60 @@ def test_kernel_variants_agree(pc, monkeypatch):
             assert np.array_equal(x, y), name
 
 
+@pytest.mark.parametrize("hw", [(72, 128), (150, 200), (34, 66), (16, 64), (270, 480), (2, 2), (18, 1000)])
+def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch):
+    """k_point_fused_seq (round 6: the half-resolution fast-bloom source of ref:605-607 formed in LDS inside the pointwise kernel) against
+    k_half_group + k_point_lean_seq (the source as a plane): identical bytes and states — every tile position (first / last column strip, a last
+    block row that hangs over the frame, frames smaller than a tile), pixel sizes 1 / 2 / 3, aberration, with and
+    without persistence, a warp behind it, half frames, and blocks of 4 / 8 / 16 wavefronts.  Frames of odd size take the two-launch path either way."""
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    h, w = hw
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = 11
+    clip_u8 = np.stack([make_frame(h, w, seed=300 + i, kind="grad" if i % 2 else "noise") for i in range(n)])
+    # (the gate-folded "lean" builds serve the reference CLI's default gate set with or without pixelate; a bloom threshold or a colour grade
+    # runs k_point_sel_seq, which this round did not touch)
+    cases = [RenderSettings(), RenderSettings(pixel_size=1), RenderSettings(pixel_size=3, aberration_px=3), RenderSettings(persistence=0.0),
+             RenderSettings(pixel_size=1, persistence=0.0, aberration_px=0, bloom_strength=0.9),
+             RenderSettings(warp_strength=0.2), RenderSettings(pixel_size=1, warp_strength=0.15, persistence=0.0, bloom_strength=0.6)]
+    outs = {}
+    for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16})):
+        monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
+        effects._tls.engines = {}
+        res, plans = [], []
+        for dtype in (torch.uint8, torch.float16):
+            frames = torch.from_numpy(clip_u8).to(dev).to(dtype)
+            for rs in cases:
+                pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=9, dtype=dtype)
+                o, st = pipe.run(frames, first_index=3)
+                plans.append(pipe.plan().get("point", ""))
+                res.append(o.cpu().numpy())
+                if st is not None:
+                    res.append(st.cpu().numpy())
+                    o2, st2 = pipe.run(frames[:5], first_index=3 + n, state=st)          # a batch that continues from a carried state
+                    res += [o2.cpu().numpy(), st2.cpu().numpy()]
+        outs[name] = (res, plans)
+    effects._tls.engines = {}
+    even = h % 2 == 0 and w % 2 == 0
+    assert all(p.startswith("k_point_fused_seq<") for p in outs["fused"][1]) == even, outs["fused"][1]
+    assert all(p.startswith("k_point_lean_seq<") for p in outs["two"][1]), outs["two"][1]
+    for name in ("two", "fused4", "fused16"):
+        assert len(outs[name][0]) == len(outs["fused"][0])
+        for k, (x, y) in enumerate(zip(outs["fused"][0], outs[name][0])):
+            assert np.array_equal(x, y), (name, k, hw)
+
+
+def test_fused_fast_bloom_odd_sizes_take_the_plane_path(pc):
+    """cv2.resize's exact 2x decimation only exists for even sizes: an odd width or height keeps the generic bilinear taps, i.e. the k_half_group plane."""
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for h, w in ((71, 128), (72, 127)):
+        pipe = FramePipeline(dev, h, w, RenderSettings(), fps=30.0, noise_seed=9)
+        pipe.run(torch.zeros((4, h, w, 3), dtype=torch.uint8, device=dev))
+        assert pipe.plan().get("point", "").startswith("k_point_lean_seq<") and pipe.plan().get("half", "").startswith("k_half_group<"), pipe.plan()
+
+
 @pytest.mark.parametrize("triad", [(0.35, 0.5), (0.35, 0.0), (0.5, 1.0), (0.2, 2.0), (1.0, 0.7)])
 @pytest.mark.parametrize("hw", [(40, 700), (90, 130), (33, 64), (20, 1)])
 def test_composite_triad_tables(pc, triad, hw, monkeypatch):

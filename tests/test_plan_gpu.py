@@ -18,7 +18,7 @@ EXPECTED = {
     3: (4, dict(phosphor="k_phosphor_ct<9,u8>", group=2, seg_rows=256, warp=WARP_PLAIN_U8, warp_frames=2)),
     4: (8, dict(phosphor="k_phosphor_ct<4,u8>", group=5, seg_rows=SEG_1080P, warp="k_warp_lean<f64,render,u8,rows=2,tile=64x8,plain>", warp_frames=4)),      # the clip's first frame passes through unblended (ref:1094-1095): a run of 4
     5: (2, dict(phosphor="k_phosphor_ct<9,half>", group=1, seg_rows=256, warp="k_warp_lean<f64,none,half,rows=4,tile=128x8,plain>", warp_frames=1)),
-    0: (8, dict(half="k_half_group<fast+pixelate,u8>", point="k_point_lean_seq<fast+pixelate,u8,render>")),      # the reference CLI's defaults
+    0: (8, dict(point="k_point_fused_seq<fast+pixelate,u8,render>")),      # the reference CLI's defaults (round 6: the half-resolution bloom source is formed inside the pointwise kernel)
 }
 
 
@@ -52,12 +52,12 @@ def test_baseline_configs_land_on_their_builds(cfg, monkeypatch):
     for key, want in EXPECTED[cfg][1].items():
         assert plan.get(key) == want, (cfg, key, plan)
     if cfg == 0:
-        assert plan.get("group", 0) >= 2 and "phosphor" not in plan and "warp" not in plan, plan
+        assert plan.get("group", 0) >= 2 and "phosphor" not in plan and "warp" not in plan and "half" not in plan, plan
 
 
 @pytest.mark.parametrize("cfg,opts,key", [(3, {"NO_CT": 1}, "phosphor"), (5, {"NO_CT": 1}, "phosphor"), (2, {"NO_CT": 1}, "phosphor"),
                                           (3, {"NO_PLAIN_WARP": 1}, "warp"), (5, {"NO_PLAIN_WARP": 1}, "warp"), (4, {"NO_PLAIN_WARP": 1}, "warp"),
-                                          (3, {"FORCE_GENERIC": 1}, "phosphor"), (0, {"FORCE_RUNTIME_FLAGS": 1}, "point")])
+                                          (3, {"FORCE_GENERIC": 1}, "phosphor"), (0, {"FORCE_RUNTIME_FLAGS": 1}, "point"), (0, {"NO_FUSED_HALF": 1}, "point")])
 def test_a_forced_fallback_is_seen(cfg, opts, key, monkeypatch):
     """The guard guards: with a build switched off the recorded plan differs from the pinned one (so the test above would fail)."""
     plan = _plan(cfg, opts, monkeypatch)
