@@ -1051,6 +1051,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
     crtfx_ctx::Plan best = {};
     auto group_done = [&]() { if (c->plan.group >= best.group) best = c->plan; };
     while (i < n) {
+        c->plan = {};                              // the record of THIS group's launches only
         // ---- grouped path: Gaussian-bloom chain on the register-window kernel, up to group_max frames per launch ----
         int g = 0;
         KGroup kg{};
@@ -1160,8 +1161,10 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 const bool pixelate = gates == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
-                // dx / dy tap tables), a block of >= 4 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tile)
-                const bool fused = lean && fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4;
+                // dx / dy tap tables), a block of 4 .. 8 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tiles of the run's
+                // frames: g * 34 * (waves + 2) * 16 bytes of dynamic LDS, 43.5 KB for 8 frames at 8 wavefronts)
+                const bool fused = lean && fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4 && waves <= 8;
+                const size_t fused_lds = (size_t)g * (TW / 2 + 2) * (waves + 2) * 16;
                 if (fastb && !fused) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
                     ProfEv ph(c, 2, g);
@@ -1183,8 +1186,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                     } while (0)
 #define CRTFX_FSEQ(SFV, PIXV)                                                                                                                            \
                     do {                                                                                                                                     \
-                        if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); } \
-                        else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), 0, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
+                        if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); } \
+                        else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
                     if (fused) {
                         if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }

@@ -563,17 +563,18 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
 // A block owns a 64 x (ROWS * waves)-pixel tile.  The bilinear 2x upsample of its pixels reads half-resolution columns x0/2 - 1 .. x0/2 + 32 and rows
 // y0/2 - 1 .. y0/2 + waves * ROWS / 2: a (34 x (waves + 2))-entry tile of ds.  Per frame, the block's first threads form one entry each — the 2 x 2 mean
 // of the graded, thresholded source pixels, half_body's arithmetic in half_body's order (with --pixel-size 2, the reference CLI's default, the four
-// samples of a cell are one pixel: fetched and graded once) — into one of TWO LDS tiles (float4 per entry), one barrier per frame:
-//     A(0) | barrier | A(1), B(0) | barrier | A(2), B(1) | ...        A(j): entries of frame j -> tile j & 1;  B(j): the thread's pixels of frame j
-// (A(j + 1) overwrites the tile B(j - 1) read: every thread finished B(j - 1) before it arrived at the barrier in front of B(j).)  Each thread then
-// takes its four taps from LDS instead of from the plane.  Exact 2x decimation only (W and H even: the host checks); same bits as the two-kernel path.
+// samples of a cell are one pixel: fetched and graded once) — for ALL nseq frames of the run, in a prologue, into nseq LDS tiles (float4 per entry;
+// dynamic LDS, nseq * 34 * (waves + 2) * 16 bytes: 43.5 KB for 8 frames and 8 wavefronts), then ONE barrier; the frame loop behind it is
+// k_point_lean_seq's, barrier-free, with the four taps of a pixel read from LDS instead of from the plane.  (The first build formed frame j + 1's tile
+// beside frame j's pixels, two tiles, one barrier per frame: 105 us per 8 1080p frames against 76 + 27 for the two launches — the per-frame barrier
+// cost more than the launch it saved, profiles/r06_fused_half_ab.txt.)  Exact 2x decimation only (W and H even: the host checks); same bits as the
+// two-kernel path.
 constexpr int FUSED_TWH = TW / 2 + 2;                       // 34 half-resolution columns per 64-pixel tile
-constexpr int FUSED_MAX_ENT = FUSED_TWH * (16 * CRTFX_POINT_ROWS / 2 + 2);      // 16 waves: 34 x 18 = 612 entries
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G, int nseq) {
     static_assert((SF & CRTFX_F_BLOOM_FAST) != 0 && CRTFX_POINT_ROWS == 2, "the fused build is the fast-bloom chain, two rows per thread");
     __shared__ float lut[2 * LUT_STRIDE];
-    __shared__ float4 dst[2][FUSED_MAX_ENT];
+    extern __shared__ float4 dst[];                // [nseq][34 * (waves + 2)]
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
     P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
@@ -609,26 +610,47 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         ea[0] = (uint32_t)xr0 * 3u; ea[1] = (uint32_t)mx0 * 3u + 1u; ea[2] = (uint32_t)xb0 * 3u + 2u;
         ea[3] = (uint32_t)xr1 * 3u; ea[4] = (uint32_t)mx1 * 3u + 1u; ea[5] = (uint32_t)xb1 * 3u + 2u;
     }
-    // a1..a4 of one source pixel (= fetch_graded_mapped without an overlay: the lean build has none) and its bloom source (ref:601-604)
-    auto src_px = [&](const KFrame& F, uint32_t row, uint32_t er_, uint32_t eg_, uint32_t eb_, float (&v)[3]) {
-        const RawRGB raw = load_raw(PIX, F.in, row + er_, row + eg_, row + eb_);
+    // a1..a4 of one source pixel from its raw samples (= fetch_graded_mapped without an overlay: the lean build has none)
+    auto graded = [&](const RawRGB& raw, float (&v)[3]) {
         if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { v[0] = P.grade_lut[raw.r]; v[1] = P.grade_lut[256 + raw.g]; v[2] = P.grade_lut[512 + raw.b]; }
         else { v[0] = norm_px(PIX, raw.r); v[1] = norm_px(PIX, raw.g); v[2] = norm_px(PIX, raw.b); grade(P, v[0], v[1], v[2]); }
     };
-    auto make_entry = [&](int jf) {
-        const KFrame F = G.f[jf];
-        float a[3], b[3], c[3], d[3];
-        src_px(F, erow0, ea[0], ea[1], ea[2], a);
-        if (same_x) { b[0] = a[0]; b[1] = a[1]; b[2] = a[2]; } else src_px(F, erow0, ea[3], ea[4], ea[5], b);
-        if (same_y) { c[0] = a[0]; c[1] = a[1]; c[2] = a[2]; } else src_px(F, erow1, ea[0], ea[1], ea[2], c);
-        if (same_x) { d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
-        else if (same_y) { d[0] = b[0]; d[1] = b[1]; d[2] = b[2]; }
-        else src_px(F, erow1, ea[3], ea[4], ea[5], d);
+    // the entry from its four graded pixels: half_body's mean4 form, its operation order (bloom source ref:601-604)
+    auto put_entry = [&](int jf, const float (&a)[3], const float (&b)[3], const float (&c)[3], const float (&d)[3]) {
         float o[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;      // = half_body, mean4
-        dst[jf & 1][threadIdx.x] = float4{o[0], o[1], o[2], 0.0f};
+        for (int k = 0; k < 3; ++k) o[k] = (((bloom_src(P, a[k]) + bloom_src(P, b[k])) + bloom_src(P, c[k])) + bloom_src(P, d[k])) * 0.25f;
+        if (jf < nseq) dst[jf * nent + (int)threadIdx.x] = float4{o[0], o[1], o[2], 0.0f};
     };
+    // The loads of ALL frames are issued before the first is consumed (a frame past the run's end reads the last frame again and stores nothing):
+    // taken frame by frame, behind `if (jf < nseq)`, the prologue was eight dependent round trips to HBM — 16 of the kernel's 95 us per 8 1080p
+    // frames (profiles/r06_fused_half_ab.txt).  Whether a wave's cells are single pixels is a wave-uniform question (pixel size 2: always).
+    const bool one_px = __ballot(maker && !(same_x && same_y)) == 0ull;
+    if (one_px) {
+        RawRGB raw[MAX_GROUP];
+#pragma unroll
+        for (int jf = 0; jf < MAX_GROUP; ++jf) raw[jf] = load_raw(PIX, G.f[min(jf, nseq - 1)].in, erow0 + ea[0], erow0 + ea[1], erow0 + ea[2]);
+        if (maker) {
+#pragma unroll
+            for (int jf = 0; jf < MAX_GROUP; ++jf) {
+                float a[3];
+                graded(raw[jf], a);
+                put_entry(jf, a, a, a, a);
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (int jf = 0; jf < nseq; ++jf) {
+            const uint8_t* in = G.f[jf].in;
+            const RawRGB ra = load_raw(PIX, in, erow0 + ea[0], erow0 + ea[1], erow0 + ea[2]), rb = load_raw(PIX, in, erow0 + ea[3], erow0 + ea[4], erow0 + ea[5]);
+            const RawRGB rc = load_raw(PIX, in, erow1 + ea[0], erow1 + ea[1], erow1 + ea[2]), rd = load_raw(PIX, in, erow1 + ea[3], erow1 + ea[4], erow1 + ea[5]);
+            if (maker) {
+                float a[3], b[3], c[3], d[3];
+                graded(ra, a); graded(rb, b); graded(rc, c); graded(rd, d);      // (equal samples give equal values: same bits as half_body's shared fetches)
+                put_entry(jf, a, b, c, d);
+            }
+        }
+    }
     // ---- the thread's own pixels (frame-invariant part: k_point_lean_seq's) ----
     int yr[ROWS];
     uint32_t t00[ROWS], t01[ROWS], t10[ROWS], t11[ROWS];      // entry indices of the four taps inside the LDS tile
@@ -665,16 +687,14 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         }
         if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
-    if (maker) make_entry(0);
+    __syncthreads();                               // the tiles and the LUTs are visible: the only barrier of the kernel
     for (int jf = 0; jf < nseq; ++jf) {
-        __syncthreads();                           // tile jf & 1 (and, the first time, the LUTs) visible; every thread is done with tile (jf + 1) & 1
-        if (maker && jf + 1 < nseq) make_entry(jf + 1);
         KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
         F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
         KOut O = G.o[jf];
         O.pix = PIX;
         const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
-        const float4* __restrict__ tile = dst[jf & 1];
+        const float4* __restrict__ tile = dst + jf * nent;
         T v[ROWS][3];
 #pragma unroll
         for (int k = 0; k < ROWS; ++k) {

@@ -14,7 +14,7 @@ print('%-34s %9.0f frames/s  repeats %s  kernels %s  plan %s' % (sys.argv[1], d[
 for rep in 1 2 3; do
   one
   one --opt NO_FUSED_HALF=1
-  one --opt POINT_TILES=16
+  one --opt POINT_TILES=6
   one --opt POINT_TILES=4
 done
 cat $F
