@@ -653,7 +653,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
     }
     // ---- the thread's own pixels (frame-invariant part: k_point_lean_seq's) ----
     int yr[ROWS];
-    uint32_t t00[ROWS], t01[ROWS], t10[ROWS], t11[ROWS];      // entry indices of the four taps inside the LDS tile
+    uint32_t t00[ROWS];                                       // entry index of a pixel's top-left tap inside the LDS tile; the others sit at + 1, + 34, + 35
     uint32_t er[ROWS], eg[ROWS], eb[ROWS];
     float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
     F3 st[ROWS];
@@ -669,13 +669,12 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         }
         {
             const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
-            const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
             a1[k] = P.ux_a[x]; a0[k] = 1.0f - a1[k]; b1[k] = P.uy_a[y]; b0[k] = 1.0f - b1[k];
-            // tile coordinates; the clamps only ever bind for rows below the frame's last block row (their pixels are not stored)
-            const int lx = min(max(sx - i0, 0), FUSED_TWH - 1), lx1 = min(max(sx1 - i0, 0), FUSED_TWH - 1);
-            const int ly = min(max(sy - j0, 0), thh - 1), ly1 = min(max(sy1 - j0, 0), thh - 1);
-            t00[k] = (uint32_t)(ly * FUSED_TWH + lx); t01[k] = (uint32_t)(ly * FUSED_TWH + lx1);
-            t10[k] = (uint32_t)(ly1 * FUSED_TWH + lx); t11[k] = (uint32_t)(ly1 * FUSED_TWH + lx1);
+            // Tile coordinates.  The right / lower tap of cv2.resize is min(s + 1, last): entry (l + 1) of the tile holds exactly that, because the
+            // tile is filled with ds(clamp(j0 + jj), clamp(i0 + ii)) — so the four taps sit at FIXED offsets from the first (one address
+            // register per pixel, immediates for the rest).  The clamps only ever bind for rows below the frame's last block row (not stored).
+            const int lx = min(max(sx - i0, 0), FUSED_TWH - 2), ly = min(max(sy - j0, 0), thh - 2);
+            t00[k] = (uint32_t)(ly * FUSED_TWH + lx);
         }
         {   // = fetch_raw's addressing (ref:573-583), frame-invariant
             int xs = x, ys = y;
@@ -708,7 +707,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
                 else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
             }
             {
-                const float4 p00 = tile[t00[k]], p01 = tile[t01[k]], p10 = tile[t10[k]], p11 = tile[t11[k]];
+                const float4* tp = tile + t00[k];
+                const float4 p00 = tp[0], p01 = tp[1], p10 = tp[FUSED_TWH], p11 = tp[FUSED_TWH + 1];
                 const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
                 const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
                 const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
