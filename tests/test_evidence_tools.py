@@ -159,8 +159,10 @@ OTHER_PINNED = {
     "crtfx::k_warp_lean<true, 0, 0, 4, false, 2, false, true>": (72, 0),      # configs 2, 3: f64, no blend, u8, 4 rows, plain (67 VGPRs: 7 waves)
     "crtfx::k_warp_lean<true, 1, 0, 2, false, 1, true, true>": (80, 0),       # config 4: persistence run, 2 rows, plain (76: 6 waves)
     "crtfx::k_warp_lean<true, 0, 1, 4, false, 2, false, true>": (80, 0),      # config 5: half rows (74: 6 waves)
-    "crtfx::k_point_lean_seq<16821680u, 0, 1>": (128, 8224),                  # the reference CLI's defaults: fast bloom + pixelate, u8, render blend (106; 1024-thread blocks)
-    "crtfx::k_half_group<16821680u, 0>": (32, 0),                             # ... and its half-resolution bloom source (24)
+    "crtfx::k_point_fused_seq<16821680u, 0, 1>": (96, 8224),                  # the reference CLI's defaults: fast bloom + pixelate, u8, render blend (90; two 512-thread blocks per CU
+                                                                              # need <= 128; + 43.5 KB of dynamic LDS per block for the eight frames' half-resolution tiles)
+    "crtfx::k_point_lean_seq<16821680u, 0, 1>": (128, 8224),                  # ... its two-launch form (odd frame sizes, NO_FUSED_HALF): 106
+    "crtfx::k_half_group<16821680u, 0>": (32, 0),                             # ... and that form's half-resolution bloom source (24)
 }
 
 
