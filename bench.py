@@ -424,9 +424,9 @@ def main():
     shard = FrameShard(world, rank, B)
     sharded_iir = p > 0.0 and use_dist
     engine = GpuShardEngine(pipe, B, slots=2 if sharded_iir else 1)
-    # the overlapped hop schedule is the default over gloo (rehearsals) only: its RCCL branch has never run on hardware
-    # (no multi-GPU box in this pipeline), and at these chunk sizes the synchronous hop costs < 2 % of a round
-    # (0.16 ms of one xGMI link + 0.17 ms of fix-up against a >= 20 ms scan); CRTFX_SHARD_OVERLAP=1 opts in.
+    # the overlapped hop schedule is the default over gloo (rehearsals) only: over RCCL it has run at world size 1 (the one-rank ring,
+    # tests/test_rccl_world1_gpu.py) but never between two GPUs, and at these chunk sizes the synchronous hop costs < 2 % of a round
+    # (0.16 ms of one xGMI link + 0.15 ms of fix-up against a >= 20 ms scan; world 1: 0.14 %); CRTFX_SHARD_OVERLAP=1 opts in.
     want_overlap = sharded_iir and (backend == "gloo" or os.environ.get("CRTFX_SHARD_OVERLAP") == "1")
     render = ShardedRender(shard, p, engine, dist=dist, overlap=want_overlap, timing=sharded_iir, loopback=bool(a.force_dist))
 
