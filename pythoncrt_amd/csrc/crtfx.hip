@@ -1134,7 +1134,12 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             const bool fastb = (fl & CRTFX_F_BLOOM) && (fl & CRTFX_F_BLOOM_FAST);
             const bool seq_ok = !gauss && !c->split && !c->force_generic &&
                                 (!warp || (size_t)c->H * c->W * 12 < ((size_t)1 << 31));      // with a warp behind it: pre-warp images parked, then k_warp_lean
-            const bool lean_gates = !c->force_runtime_flags && (gates == SF_FAST || gates == SF_FAST_PIX) && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
+            // "lean" = no per-pixel plane anywhere in the chain (full-size triad / vignette masks, coarse grain, and — checked per frame below — a 2-D
+            // scanline plane, an injected grain plane, text overlays).  The gate sets of the reference CLI's defaults have builds with the gate word
+            // folded at compile time; every other plane-free gate set (a colour grade, a bloom threshold, stages switched off, flicker, preserve-luma)
+            // runs the same kernels with the gate word at run time (SF_LEAN_RT)
+            const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
+            const bool folded_gates = gates == SF_FAST || gates == SF_FAST_PIX;
             bool lean = lean_gates;
             KGroup kg{};
             KWarpGroup wg{};                     // warp on: the frames' FINAL outputs (the point kernels then only park pre-warp images)
@@ -1168,14 +1173,14 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (fastb && !fused) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
                     ProfEv ph(c, 2, g);
-                    plan_note(c->plan.half, "k_half_group<%s,%s>", lean ? sf_name(gates) : "runtime", lean ? pix_name(c->pix_fmt) : "any");
-                    if (!lean) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
+                    plan_note(c->plan.half, "k_half_group<%s,%s>", (lean && folded_gates) ? sf_name(gates) : "runtime", (lean && folded_gates) ? pix_name(c->pix_fmt) : "any");
+                    if (!lean || !folded_gates) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
                     else if (pixelate) { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                     else { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                 }
                 ProfEv pe(c, 0, g);
                 c->plan.group = g;
-                if (lean) plan_note(c->plan.point, "%s<%s,%s,%s>", fused ? "k_point_fused_seq" : "k_point_lean_seq", sf_name(gates), pix_name(c->pix_fmt), blend_name(kg.o[0].blend == CRTFX_BLEND_RENDER ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE));
+                if (lean) plan_note(c->plan.point, "%s<%s,%s,%s>", fused ? "k_point_fused_seq" : "k_point_lean_seq", folded_gates ? sf_name(gates) : "runtime", pix_name(c->pix_fmt), blend_name(kg.o[0].blend == CRTFX_BLEND_RENDER ? CRTFX_BLEND_RENDER : CRTFX_BLEND_NONE));
                 else plan_note(c->plan.point, "k_point_sel_seq<%s,%s>", pix_name(c->pix_fmt), (!(fl & CRTFX_F_PIXELATE) && !fastb) ? "one-round" : "two-round");
                 if (lean) {
                     dim3 gp((c->W + TW - 1) / TW, (c->H + waves * CRTFX_POINT_ROWS - 1) / (waves * CRTFX_POINT_ROWS));
@@ -1190,9 +1195,11 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
                     if (fused) {
-                        if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
+                        if (!folded_gates) { if (f16) CRTFX_FSEQ(SF_LEAN_RT, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_LEAN_RT, CRTFX_PIX_U8); }
+                        else if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
                         else { if (f16) CRTFX_FSEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST, CRTFX_PIX_U8); }
                     }
+                    else if (!folded_gates) { if (f16) CRTFX_SEQ(SF_LEAN_RT, CRTFX_PIX_F16); else CRTFX_SEQ(SF_LEAN_RT, CRTFX_PIX_U8); }
                     else if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
                     else { if (f16) CRTFX_SEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST, CRTFX_PIX_U8); }
 #undef CRTFX_FSEQ

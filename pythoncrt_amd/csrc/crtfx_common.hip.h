@@ -103,6 +103,7 @@ constexpr uint32_t SF_FULL_GATES = CRTFX_F_BLOOM | CRTFX_F_TRIAD | CRTFX_F_TRIAD
 // ... with the fast half-res bloom (the reference CLI's default), without / with pixelate
 constexpr uint32_t SF_FAST = SF_FULL_GATES | CRTFX_F_BLOOM_FAST;
 constexpr uint32_t SF_FAST_PIX = SF_FAST | CRTFX_F_PIXELATE;
+constexpr uint32_t SF_LEAN_RT = 0xFFFFFFFEu;      // template value of the lean pointwise kernels: the gate word is read at run time (any plane-free gate set)
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
 constexpr int NB = 8;             // rows per H-pass block / register-blocked V outputs

@@ -445,13 +445,20 @@ __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KO
 // once.  Frame jf's half-res bloom source sits in slot jf of the scratch (k_half_group).  Same operations per pixel in
 // the same order as k_point_lean<SF, PIX, CRTFX_BLEND_RENDER> frame by frame: the same bits.
 // BLENDM = CRTFX_BLEND_NONE: the same grouping for independent frames (persistence 0): no state, the rest as above.
+// SF = SF_LEAN_RT (round 6): the same kernel with the gate word left at run time (wave-uniform branches) — every setting of the reference CLI
+// that needs no per-pixel plane: a colour grade, a bloom threshold, any of triad / scanlines / vignette / grain off, flicker, preserve-luma.
+// One knob away from the defaults used to mean the general k_point_sel_seq at half the frame rate (profiles/r06_cli_variants.txt).
+template <uint32_t SF>
+__device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) { if constexpr (SF == SF_LEAN_RT) return Pin.flags & ~(uint32_t)CRTFX_F_WARP; else return SF; }
+
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, int nseq) {
     __shared__ float lut[2 * LUT_STRIDE];
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
-    P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
-    if constexpr ((SF & CRTFX_F_TRIAD) && (SF & CRTFX_F_TRIAD_LUT)) {
+    P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    const bool fastb = (P.flags & CRTFX_F_BLOOM) && (P.flags & CRTFX_F_BLOOM_FAST);      // (compile-time in the folded builds)
+    if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
         __syncthreads();
     }
@@ -461,7 +468,6 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
     const int ybase = blockIdx.y * (waves * ROWS) + (threadIdx.x >> 6);
     if (ybase >= P.H) return;
     const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
-    using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
     int yr[ROWS];
     uint32_t o00[ROWS], o01[ROWS], o10[ROWS], o11[ROWS];      // BYTE offsets of the four half-res taps inside a slot (32-bit: the loads take scalar base + vector offset)
     uint32_t er[ROWS], eg[ROWS], eb[ROWS];                    // element offsets of the pixel's three samples inside a frame (pixelate map and aberration wrap resolved once)
@@ -477,7 +483,8 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
             F0.scan_plane = nullptr;
             M0[k] = load_masks(P, F0, y, x);
         }
-        if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
+        o00[k] = o01[k] = o10[k] = o11[k] = 0u; a0[k] = a1[k] = b0[k] = b1[k] = 0.0f;
+        if (fastb) {
             const int sx = P.ux_ofs[x], sy = P.uy_ofs[y];
             const int sx1 = min(sx + 1, P.hw - 1), sy1 = min(sy + 1, P.hh - 1);
             a1[k] = P.ux_a[x]; a0[k] = 1.0f - a1[k]; b1[k] = P.uy_a[y]; b0[k] = 1.0f - b1[k];
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
         }
         {   // = fetch_raw's addressing (ref:573-583), frame-invariant
             int xs = x, ys = y;
-            if constexpr ((SF & CRTFX_F_PIXELATE) != 0) { xs = P.xmap[x]; ys = P.ymap[y]; }
+            if (P.flags & CRTFX_F_PIXELATE) { xs = P.xmap[x]; ys = P.ymap[y]; }
             const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
             int xr = xs, xb = xs;
             if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }
@@ -495,99 +502,105 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
         if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
     const size_t slot = (size_t)P.hh * P.hw * 3;
-    for (int jf = 0; jf < nseq; ++jf) {
-        KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
-        F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
-        KOut O = G.o[jf];
-        O.pix = PIX;
-        const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
-        const float* __restrict__ ds = P.ds + (size_t)jf * slot;
-        T v[ROWS][3];
+    // the frames of the run, in the image type the reference has at this point: float64 once the vignette / flicker promotes (ref:626-633)
+    auto run = [&](auto tzero) {
+        using T = decltype(tzero);
+        for (int jf = 0; jf < nseq; ++jf) {
+            KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
+            F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+            KOut O = G.o[jf];
+            O.pix = PIX;
+            const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
+            const float* __restrict__ ds = P.ds + (size_t)jf * slot;
+            T v[ROWS][3];
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const int y = yr[k];
-            PixMasks M = M0[k];
-            if constexpr ((SF & CRTFX_F_SCANLINES) != 0) M.sl = F.scan_row[y];
-            float r, g, b;
-            {   // = fetch_graded (no overlay in the lean build)
-                const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
-                if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
-                else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+            for (int k = 0; k < ROWS; ++k) {
+                const int y = yr[k];
+                PixMasks M = M0[k];
+                if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
+                float r, g, b;
+                {   // = fetch_graded (no overlay in the lean build)
+                    const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
+                    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+                    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+                }
+                if (fastb) {
+                    const char* dsb = reinterpret_cast<const char*>(ds);
+                    const F3 p00 = *reinterpret_cast<const F3*>(dsb + o00[k]);
+                    const F3 p01 = *reinterpret_cast<const F3*>(dsb + o01[k]);
+                    const F3 p10 = *reinterpret_cast<const F3*>(dsb + o10[k]);
+                    const F3 p11 = *reinterpret_cast<const F3*>(dsb + o11[k]);
+                    const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
+                    const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
+                    const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
+                    r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+                }
+                tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
             }
-            if constexpr ((SF & CRTFX_F_BLOOM_FAST) != 0) {
-                const char* dsb = reinterpret_cast<const char*>(ds);
-                const F3 p00 = *reinterpret_cast<const F3*>(dsb + o00[k]);
-                const F3 p01 = *reinterpret_cast<const F3*>(dsb + o01[k]);
-                const F3 p10 = *reinterpret_cast<const F3*>(dsb + o10[k]);
-                const F3 p11 = *reinterpret_cast<const F3*>(dsb + o11[k]);
-                const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
-                const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
-                const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
-                r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+            const T p = (T)O.p, q = (T)O.q;
+            if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k)
+                    if (ybase + k * waves < P.H)
+                        *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
+                continue;
             }
-            tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
-        }
-        const T p = (T)O.p, q = (T)O.q;
-        if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
 #pragma unroll
-            for (int k = 0; k < ROWS; ++k)
-                if (ybase + k * waves < P.H)
-                    *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
-            continue;
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if (ybase + k * waves < P.H) {           // wave-uniform
-                const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
-                float f0, f1, f2;
-                if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
-                    f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
-                    f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
-                    f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
-                    st[k] = F3{f0, f1, f2};
-                } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
-                if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
-                if (O.out_u8) {
-                    PackedPix pk;
-                    if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
-                    else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
-                    store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+            for (int k = 0; k < ROWS; ++k) {
+                if (ybase + k * waves < P.H) {           // wave-uniform
+                    const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
+                    float f0, f1, f2;
+                    if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
+                        f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
+                        f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
+                        f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
+                        st[k] = F3{f0, f1, f2};
+                    } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
+                    if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
+                    if (O.out_u8) {
+                        PackedPix pk;
+                        if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+                        else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
+                        store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+                    }
                 }
             }
         }
-    }
+    };
+    if constexpr (SF == SF_LEAN_RT) { if (promotes(P)) run(0.0); else run(0.0f); }
+    else if constexpr ((SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0) run(0.0);
+    else run(0.0f);
 }
 
 // k_point_fused_seq — k_point_lean_seq with the fast-bloom source formed INSIDE the kernel (round 6): no k_half_group launch in front of it, no
 // quarter-size plane in memory, the frame fetched once.  (ref:605-607: ds = cv2.resize(src, (W//2, H//2)); blur = cv2.resize(ds, (W, H)).)
 // A block owns a 64 x (ROWS * waves)-pixel tile.  The bilinear 2x upsample of its pixels reads half-resolution columns x0/2 - 1 .. x0/2 + 32 and rows
-// y0/2 - 1 .. y0/2 + waves * ROWS / 2: a (34 x (waves + 2))-entry tile of ds.  Per frame, the block's first threads form one entry each — the 2 x 2 mean
+// y0/2 - 1 .. y0/2 + waves * ROWS / 2: a (34 x (waves + 2))-entry tile of ds.  The block's first threads form one entry each — the 2 x 2 mean
 // of the graded, thresholded source pixels, half_body's arithmetic in half_body's order (with --pixel-size 2, the reference CLI's default, the four
 // samples of a cell are one pixel: fetched and graded once) — for ALL nseq frames of the run, in a prologue, into nseq LDS tiles (float4 per entry;
 // dynamic LDS, nseq * 34 * (waves + 2) * 16 bytes: 43.5 KB for 8 frames and 8 wavefronts), then ONE barrier; the frame loop behind it is
 // k_point_lean_seq's, barrier-free, with the four taps of a pixel read from LDS instead of from the plane.  (The first build formed frame j + 1's tile
 // beside frame j's pixels, two tiles, one barrier per frame: 105 us per 8 1080p frames against 76 + 27 for the two launches — the per-frame barrier
 // cost more than the launch it saved, profiles/r06_fused_half_ab.txt.)  Exact 2x decimation only (W and H even: the host checks); same bits as the
-// two-kernel path.
+// two-kernel path.  SF = SF_LEAN_RT: the gate word at run time, as in k_point_lean_seq (the host launches this kernel only with fast bloom on).
 constexpr int FUSED_TWH = TW / 2 + 2;                       // 34 half-resolution columns per 64-pixel tile
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G, int nseq) {
-    static_assert((SF & CRTFX_F_BLOOM_FAST) != 0 && CRTFX_POINT_ROWS == 2, "the fused build is the fast-bloom chain, two rows per thread");
+    static_assert((SF == SF_LEAN_RT || (SF & CRTFX_F_BLOOM_FAST) != 0) && CRTFX_POINT_ROWS == 2, "the fused build is the fast-bloom chain, two rows per thread");
     __shared__ float lut[2 * LUT_STRIDE];
     extern __shared__ float4 dst[];                // [nseq][34 * (waves + 2)]
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
-    P.flags = SF; P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
-    if constexpr ((SF & CRTFX_F_TRIAD) && (SF & CRTFX_F_TRIAD_LUT)) {
+    P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
     }
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
     const int waves = blockDim.x >> 6;
     const int y0 = blockIdx.y * (waves * ROWS);
-    const int ybase = y0 + (threadIdx.x >> 6);     // (a wave whose rows all lie below the frame stays: it takes part in the barriers and stores nothing)
+    const int ybase = y0 + (threadIdx.x >> 6);     // (a wave whose rows all lie below the frame stays: it takes part in the barrier and stores nothing)
     const int x = min(x0 + lane, P.W - 1);       // lanes past the right edge redo the last pixel: same values, same stores
-    using T = typename std::conditional<(SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0, double, float>::type;
     // ---- the entry of the half-resolution tile this thread forms (frame-invariant addressing) ----
     const int i0 = (x0 >> 1) - 1, j0 = (y0 >> 1) - 1;
     const int thh = (waves * ROWS) / 2 + 2;
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         const int ii = (int)threadIdx.x % FUSED_TWH, jj = (int)threadIdx.x / FUSED_TWH;
         const int i = min(max(i0 + ii, 0), P.hw - 1), j = min(max(j0 + jj, 0), P.hh - 1);
         int mx0 = 2 * i, mx1 = 2 * i + 1, my0 = 2 * j, my1 = 2 * j + 1;
-        if constexpr ((SF & CRTFX_F_PIXELATE) != 0) {
+        if (P.flags & CRTFX_F_PIXELATE) {
             mx0 = P.xmap[mx0]; mx1 = P.xmap[mx1]; my0 = P.ymap[my0]; my1 = P.ymap[my1];
             same_x = mx1 == mx0; same_y = my1 == my0;       // pixel size 2: all four samples of the cell are one pixel
         }
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         }
         {   // = fetch_raw's addressing (ref:573-583), frame-invariant
             int xs = x, ys = y;
-            if constexpr ((SF & CRTFX_F_PIXELATE) != 0) { xs = P.xmap[x]; ys = P.ymap[y]; }
+            if (P.flags & CRTFX_F_PIXELATE) { xs = P.xmap[x]; ys = P.ymap[y]; }
             const uint32_t row = (uint32_t)ys * (uint32_t)P.W * 3u;
             int xr = xs, xb = xs;
             if (P.ab != 0) { xr = wrap(xs - P.ab, P.W); xb = wrap(xs + P.ab, P.W); }
@@ -687,64 +700,70 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         if constexpr (BLENDM == CRTFX_BLEND_RENDER) st[k] = *reinterpret_cast<const F3*>(state_in + ((uint32_t)y * (uint32_t)P.W + (uint32_t)x) * 3u);
     }
     __syncthreads();                               // the tiles and the LUTs are visible: the only barrier of the kernel
-    for (int jf = 0; jf < nseq; ++jf) {
-        KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
-        F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
-        KOut O = G.o[jf];
-        O.pix = PIX;
-        const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
-        const float4* __restrict__ tile = dst + jf * nent;
-        T v[ROWS][3];
+    auto run = [&](auto tzero) {
+        using T = decltype(tzero);
+        for (int jf = 0; jf < nseq; ++jf) {
+            KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
+            F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+            KOut O = G.o[jf];
+            O.pix = PIX;
+            const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
+            const float4* __restrict__ tile = dst + jf * nent;
+            T v[ROWS][3];
 #pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            const int y = yr[k];
-            PixMasks M = M0[k];
-            if constexpr ((SF & CRTFX_F_SCANLINES) != 0) M.sl = F.scan_row[y];
-            float r, g, b;
-            {   // = fetch_graded (no overlay in the lean build)
-                const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
-                if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
-                else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+            for (int k = 0; k < ROWS; ++k) {
+                const int y = yr[k];
+                PixMasks M = M0[k];
+                if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
+                float r, g, b;
+                {   // = fetch_graded (no overlay in the lean build)
+                    const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
+                    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+                    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+                }
+                {
+                    const float4* tp = tile + t00[k];
+                    const float4 p00 = tp[0], p01 = tp[1], p10 = tp[FUSED_TWH], p11 = tp[FUSED_TWH + 1];
+                    const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
+                    const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
+                    const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
+                    r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+                }
+                tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
             }
-            {
-                const float4* tp = tile + t00[k];
-                const float4 p00 = tp[0], p01 = tp[1], p10 = tp[FUSED_TWH], p11 = tp[FUSED_TWH + 1];
-                const float bl0 = (p00.x * a0[k] + p01.x * a1[k]) * b0[k] + (p10.x * a0[k] + p11.x * a1[k]) * b1[k];
-                const float bl1 = (p00.y * a0[k] + p01.y * a1[k]) * b0[k] + (p10.y * a0[k] + p11.y * a1[k]) * b1[k];
-                const float bl2 = (p00.z * a0[k] + p01.z * a1[k]) * b0[k] + (p10.z * a0[k] + p11.z * a1[k]) * b1[k];
-                r = clip01(r + P.bloom_strength * bl0); g = clip01(g + P.bloom_strength * bl1); b = clip01(b + P.bloom_strength * bl2);   // ref:611
+            const T p = (T)O.p, q = (T)O.q;
+            if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k)
+                    if (ybase + k * waves < P.H)
+                        *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
+                continue;
             }
-            tail_masks<T, false>(P, F, y, x, M, r, g, b, lut, lut + LUT_STRIDE, v[k][0], v[k][1], v[k][2]);
-        }
-        const T p = (T)O.p, q = (T)O.q;
-        if (O.pre) {                                 // a warp follows: park the pre-warp pixels of this frame for k_warp_lean
 #pragma unroll
-            for (int k = 0; k < ROWS; ++k)
-                if (ybase + k * waves < P.H)
-                    *reinterpret_cast<F3*>(O.pre + ((uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x) * 3u) = F3{(float)v[k][0], (float)v[k][1], (float)v[k][2]};
-            continue;
-        }
-#pragma unroll
-        for (int k = 0; k < ROWS; ++k) {
-            if (ybase + k * waves < P.H) {           // wave-uniform
-                const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
-                float f0, f1, f2;
-                if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
-                    f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
-                    f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
-                    f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
-                    st[k] = F3{f0, f1, f2};
-                } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
-                if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
-                if (O.out_u8) {
-                    PackedPix pk;
-                    if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
-                    else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
-                    store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+            for (int k = 0; k < ROWS; ++k) {
+                if (ybase + k * waves < P.H) {           // wave-uniform
+                    const uint32_t pix = (uint32_t)yr[k] * (uint32_t)P.W + (uint32_t)x;
+                    float f0, f1, f2;
+                    if constexpr (BLENDM == CRTFX_BLEND_RENDER) {
+                        f0 = (float)clip01(p * (T)st[k].x + q * v[k][0]);      // ref:1092
+                        f1 = (float)clip01(p * (T)st[k].y + q * v[k][1]);
+                        f2 = (float)clip01(p * (T)st[k].z + q * v[k][2]);
+                        st[k] = F3{f0, f1, f2};
+                    } else { f0 = (float)v[k][0]; f1 = (float)v[k][1]; f2 = (float)v[k][2]; }
+                    if (O.state && (keep_state || BLENDM != CRTFX_BLEND_RENDER)) { float* sp = O.state + pix * 3u; sp[0] = f0; sp[1] = f1; sp[2] = f2; }
+                    if (O.out_u8) {
+                        PackedPix pk;
+                        if constexpr (PIX == CRTFX_PIX_F16) { pk.lo = quant_f16(f0) | (quant_f16(f1) << 16); pk.hi = quant_f16(f2); }
+                        else { pk.lo = quant_u8x3(f0, f1, f2); pk.hi = 0; }
+                        store_row_pix(O, (size_t)yr[k] * P.W + x0, lane, min(64, P.W - x0), pk);
+                    }
                 }
             }
         }
-    }
+    };
+    if constexpr (SF == SF_LEAN_RT) { if (promotes(P)) run(0.0); else run(0.0f); }
+    else if constexpr ((SF & (CRTFX_F_VIGNETTE | CRTFX_F_FLICKER)) != 0) run(0.0);
+    else run(0.0f);
 }
 #endif  // CRTFX_MAIN_TU
 

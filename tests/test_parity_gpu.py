@@ -513,13 +513,19 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
     dev = torch.device("cuda", torch.cuda.current_device())
     n = 11
     clip_u8 = np.stack([make_frame(h, w, seed=300 + i, kind="grad" if i % 2 else "noise") for i in range(n)])
-    # (the gate-folded "lean" builds serve the reference CLI's default gate set with or without pixelate; a bloom threshold or a colour grade
-    # runs k_point_sel_seq, which this round did not touch)
+    # the gate-folded builds (the reference CLI's default gate set with or without pixelate) ...
     cases = [RenderSettings(), RenderSettings(pixel_size=1), RenderSettings(pixel_size=3, aberration_px=3), RenderSettings(persistence=0.0),
              RenderSettings(pixel_size=1, persistence=0.0, aberration_px=0, bloom_strength=0.9),
-             RenderSettings(warp_strength=0.2), RenderSettings(pixel_size=1, warp_strength=0.15, persistence=0.0, bloom_strength=0.6)]
+             RenderSettings(warp_strength=0.2), RenderSettings(pixel_size=1, warp_strength=0.15, persistence=0.0, bloom_strength=0.6),
+             # ... and the run-time-gate builds (SF_LEAN_RT): one knob away from the defaults — a colour grade (table and arithmetic forms), a bloom
+             # threshold, stages switched off (no vignette: the chain stays float32), flicker, preserve-luma
+             RenderSettings(brightness=0.05, contrast=1.1), RenderSettings(saturation=1.3, gamma=1.8, temperature=0.2, pixel_size=1),
+             RenderSettings(bloom_threshold=0.3, persistence=0.0), RenderSettings(vignette_strength=0.0, noise_strength=0.0),
+             RenderSettings(triad_strength=0.0, scanline_strength=0.0, pixel_size=3), RenderSettings(flicker_strength=0.2, flicker_hz=50.0, triad_preserve_luma=True),
+             RenderSettings(vignette_strength=0.0, persistence=0.0, gamma=0.8, warp_strength=0.1)]
     outs = {}
-    for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16})):
+    for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16}),
+                       ("general", {"FORCE_RUNTIME_FLAGS": 1})):      # k_half_group<runtime> + k_point_sel_seq: the kernels every gate set ran on before round 6
         monkeypatch.setattr(effects, "DEBUG_OPTIONS", dict(opts))
         effects._tls.engines = {}
         res, plans = [], []
@@ -540,7 +546,10 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
     even = h % 2 == 0 and w % 2 == 0
     assert all(p.startswith("k_point_fused_seq<") for p in outs["fused"][1]) == even, outs["fused"][1]
     assert not any(p.startswith("k_point_fused_seq<") for p in outs["two"][1]), outs["two"][1]
-    for name in ("two", "fused4", "fused16"):
+    assert not any(p.startswith(("k_point_fused_seq<", "k_point_lean_seq<")) for p in outs["general"][1]), outs["general"][1]
+    if even:
+        assert sum(p.startswith("k_point_fused_seq<runtime") for p in outs["fused"][1]) == 2 * 6, outs["fused"][1]      # six plane-free, warp-free gate sets x two pixel formats
+    for name in ("two", "fused4", "fused16", "general"):
         assert len(outs[name][0]) == len(outs["fused"][0])
         for k, (x, y) in enumerate(zip(outs["fused"][0], outs[name][0])):
             assert np.array_equal(x, y), (name, k, hw)
