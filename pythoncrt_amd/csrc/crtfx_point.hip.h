@@ -449,7 +449,11 @@ __global__ __launch_bounds__(1024) void k_point_lean(KParams Pin, KFrame Fin, KO
 // that needs no per-pixel plane: a colour grade, a bloom threshold, any of triad / scanlines / vignette / grain off, flicker, preserve-luma.
 // One knob away from the defaults used to mean the general k_point_sel_seq at half the frame rate (profiles/r06_cli_variants.txt).
 template <uint32_t SF>
-__device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) { if constexpr (SF == SF_LEAN_RT) return Pin.flags & ~(uint32_t)CRTFX_F_WARP; else return SF; }
+__device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) {
+    if constexpr (SF == SF_LEAN_RT) return Pin.flags & ~(uint32_t)CRTFX_F_WARP;
+    else if constexpr ((SF & KF_GRADE_RT) != 0) return (SF & ~KF_GRADE_RT) | (Pin.flags & GRADE_RT_MASK);
+    else return SF;
+}
 
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, int nseq) {
@@ -644,15 +648,31 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
 #pragma unroll
         for (int jf = 0; jf < MAX_GROUP; ++jf) raw[jf] = load_raw(PIX, G.f[min(jf, nseq - 1)].in, erow0 + ea[0], erow0 + ea[1], erow0 + ea[2]);
         if (maker) {
+            if constexpr (SF == SF_LEAN_RT || (SF & KF_GRADE_RT) != 0) {
+                // a colour grade at run time: its code (three inlined powf) once, not once per frame — unrolled, the kernel was 101 KB of code,
+                // past the instruction cache.  The raw samples wait in the entry's own LDS slot (a rolled loop cannot index registers).
 #pragma unroll
-            for (int jf = 0; jf < MAX_GROUP; ++jf) {
-                float a[3];
-                graded(raw[jf], a);
-                put_entry(jf, a, a, a, a);
+                for (int jf = 0; jf < MAX_GROUP; ++jf)
+                    if (jf < nseq) dst[jf * nent + (int)threadIdx.x] = float4{__uint_as_float(raw[jf].r), __uint_as_float(raw[jf].g), __uint_as_float(raw[jf].b), 0.0f};
+#pragma unroll 1
+                for (int jf = 0; jf < nseq; ++jf) {
+                    const float4 w = dst[jf * nent + (int)threadIdx.x];
+                    const RawRGB rw{__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z)};
+                    float a[3];
+                    graded(rw, a);
+                    put_entry(jf, a, a, a, a);
+                }
+            } else {
+#pragma unroll
+                for (int jf = 0; jf < MAX_GROUP; ++jf) {
+                    float a[3];
+                    graded(raw[jf], a);
+                    put_entry(jf, a, a, a, a);
+                }
             }
         }
     } else {
-#pragma unroll 2
+#pragma unroll 1
         for (int jf = 0; jf < nseq; ++jf) {
             const uint8_t* in = G.f[jf].in;
             const RawRGB ra = load_raw(PIX, in, erow0 + ea[0], erow0 + ea[1], erow0 + ea[2]), rb = load_raw(PIX, in, erow0 + ea[3], erow0 + ea[4], erow0 + ea[5]);

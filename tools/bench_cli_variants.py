@@ -66,9 +66,14 @@ def main():
             _, st = pipe.run(frames, first_index=(r + 1) * a.frames, state=st, out=out)
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
+        pipe.profile(1)                       # HIP events on every launch of one more run: kernel time per launch, by class
+        pipe.run(frames, first_index=(a.reps + 1) * a.frames, state=st, out=out)
+        torch.cuda.synchronize()
+        kt = {k: f"{v[0] * 1e3:.1f} us / {v[2] / max(1, v[1]):.0f} fr" for k, v in pipe.profile_read().items() if v[1]}
+        pipe.profile(False)
         plan = pipe.plan()
         builds = " + ".join(str(plan[k]) for k in ("blur", "half", "phosphor", "point", "warp") if plan.get(k))
-        print(f"{name:30s} {a.frames / best:10.0f} frames/s   group {plan.get('group')}   {builds}", flush=True)
+        print(f"{name:30s} {a.frames / best:10.0f} frames/s   group {plan.get('group')}   {builds}   {kt}", flush=True)
         del pipe
 
 
