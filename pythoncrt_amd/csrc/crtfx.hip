@@ -1139,13 +1139,13 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             // folded at compile time; every other plane-free gate set (a colour grade, a bloom threshold, stages switched off, flicker, preserve-luma)
             // runs the same kernels with the gate word at run time (SF_LEAN_RT)
             const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
-#ifdef CRTFX_EXP_FORCE_GRADE_RT
-            const bool folded_gates = false;       // timing experiment: the defaults on the run-time-grade build
-#else
             const bool folded_gates = gates == SF_FAST || gates == SF_FAST_PIX;
-#endif
             const uint32_t core = gates & ~GRADE_RT_MASK;                    // ... without the purely arithmetic gates
-            const bool grade_rt = !folded_gates && (core == SF_FAST || core == SF_FAST_PIX);      // the defaults' loads + a grade / threshold / flicker at run time
+            const bool grade_any = !folded_gates && (core == SF_FAST || core == SF_FAST_PIX);     // the defaults' loads + a grade / threshold / luma / flicker
+            // ... of which: uint8 frames whose only extra gates are per-channel grade stages (no saturation) read a1 + a4 from the host's table
+            const bool grade_lut = grade_any && c->pix_fmt == CRTFX_PIX_U8 && c->kp.grade_lut != nullptr &&
+                                   (gates & GRADE_RT_MASK & ~(uint32_t)(CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA)) == 0;
+            const bool grade_rt = grade_any && !grade_lut;
             bool lean = lean_gates;
             KGroup kg{};
             KWarpGroup wg{};                     // warp on: the frames' FINAL outputs (the point kernels then only park pre-warp images)
@@ -1170,7 +1170,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = core == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                const char* gname = folded_gates ? sf_name(gates) : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
+                const char* gname = folded_gates ? sf_name(gates) : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
+                                    : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
                 // dx / dy tap tables), a block of 4 .. 8 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tiles of the run's
@@ -1202,7 +1203,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
                     if (fused) {
-                        if (grade_rt) {
+                        if (grade_lut) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_LUT, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_GRADE_LUT, CRTFX_PIX_U8); }
+                        else if (grade_rt) {
                             if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_U8); }
                             else { if (f16) CRTFX_FSEQ(SF_FAST | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST | KF_GRADE_RT, CRTFX_PIX_U8); }
                         }
@@ -1210,6 +1212,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         else if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
                         else { if (f16) CRTFX_FSEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST, CRTFX_PIX_U8); }
                     }
+                    else if (grade_lut) { if (pixelate) CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_LUT, CRTFX_PIX_U8); else CRTFX_SEQ(SF_FAST | KF_GRADE_LUT, CRTFX_PIX_U8); }
                     else if (grade_rt) {
                         if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_U8); }
                         else { if (f16) CRTFX_SEQ(SF_FAST | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST | KF_GRADE_RT, CRTFX_PIX_U8); }

@@ -108,6 +108,10 @@ constexpr uint32_t SF_LEAN_RT = 0xFFFFFFFEu;      // template value of the lean 
 // the purely arithmetic ones — the colour grade, the bloom threshold, preserve-luma, flicker — read at run time: SF = SF_FAST[_PIX] | KF_GRADE_RT.
 // The folded body stays one basic block per stage with its loads issued together; a grade costs its arithmetic and a few scalar branches.
 constexpr uint32_t KF_GRADE_RT = 1u << 30;
+// ... and, for uint8 frames graded WITHOUT a saturation change (every other stage of apply_color_adjustments is per channel, ref:292-304): the whole of
+// a1 + a4 as one 3 x 256-entry table read (KParams::grade_lut, built on the host with the reference's own expressions) — no run-time branch at
+// all, the body stays one basic block: SF = SF_FAST[_PIX] | KF_GRADE_LUT.  Brightness / contrast / gamma / temperature: the knobs users turn first.
+constexpr uint32_t KF_GRADE_LUT = 1u << 29;
 constexpr uint32_t GRADE_RT_MASK = CRTFX_F_SATURATION | CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA | CRTFX_F_BLOOM_THR | CRTFX_F_TRIAD_LUMA | CRTFX_F_FLICKER;
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)
@@ -180,33 +184,23 @@ __device__ __forceinline__ void fetch_rgb(const KParams& P, const uint8_t* __res
 }
 
 // a4 — apply_color_adjustments (ref:279-305), float32 throughout.
-// CRTFX_STAGE_BRANCH: an empty volatile asm at the head of a stage that a RUN-TIME gate switches (the kernels with P.flags left at run time).  The
-// gate is wave-uniform, so the stage should cost one scalar branch when it is off; without the marker LLVM if-converts the cheaper stages — both
-// sides computed, v_cndmask per value — and an "off" grade / threshold / preserve-luma is paid for on every pixel (round 6: 441 v_cndmask and
-// 106 division instructions in k_point_fused_seq<fast+grade> against 32 and 2 in the folded build).  In a build with the gate folded the block is
-// either gone or unconditional, and the marker emits nothing.
-#define CRTFX_STAGE_BRANCH() asm volatile("")
 __device__ __forceinline__ void grade(const KParams& P, float& r, float& g, float& b) {
     if (P.flags & CRTFX_F_SATURATION) {
-        CRTFX_STAGE_BRANCH();
         const float luma = (0.2126f * r + 0.7152f * g) + 0.0722f * b;
         r = clip01(luma + (r - luma) * P.sat);
         g = clip01(luma + (g - luma) * P.sat);
         b = clip01(luma + (b - luma) * P.sat);
     }
     if (P.flags & CRTFX_F_TEMPERATURE) {
-        CRTFX_STAGE_BRANCH();
         r = clip01(r * P.r_gain);
         b = clip01(b * P.b_gain);
     }
     if (P.flags & CRTFX_F_BRIGHTCON) {
-        CRTFX_STAGE_BRANCH();
         r = clip01(((r - 0.5f) * P.contrast + 0.5f) + P.brightness);
         g = clip01(((g - 0.5f) * P.contrast + 0.5f) + P.brightness);
         b = clip01(((b - 0.5f) * P.contrast + 0.5f) + P.brightness);
     }
     if (P.flags & CRTFX_F_GAMMA) {
-        CRTFX_STAGE_BRANCH();
         r = clip01(powf(r, P.inv_gamma));
         g = clip01(powf(g, P.inv_gamma));
         b = clip01(powf(b, P.inv_gamma));
@@ -242,7 +236,7 @@ __device__ __forceinline__ void fetch_graded(const KParams& P, const KFrame& F, 
 
 // bloom source (ref:601-604)
 __device__ __forceinline__ float bloom_src(const KParams& P, float v) {
-    if (P.flags & CRTFX_F_BLOOM_THR) { CRTFX_STAGE_BRANCH(); return clip01((v - P.thr) / P.thr_den); }
+    if (P.flags & CRTFX_F_BLOOM_THR) return clip01((v - P.thr) / P.thr_den);
     return v;
 }
 
@@ -310,8 +304,7 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
             const float l0 = lut_g[lut_index_unit(r)], l1 = lut_g[lut_index_unit(g)], l2 = lut_g[lut_index_unit(b)];
             float q0 = l0 * M.m0, q1 = l1 * M.m1, q2 = l2 * M.m2;
             if (P.flags & CRTFX_F_TRIAD_LUMA) {
-                CRTFX_STAGE_BRANCH();
-                const float yb = (0.2126f * l0 + 0.7152f * l1) + 0.0722f * l2;
+                        const float yb = (0.2126f * l0 + 0.7152f * l1) + 0.0722f * l2;
                 const float ya = (0.2126f * q0 + 0.7152f * q1) + 0.0722f * q2;
                 float ratio = yb / fmaxf(ya, 1e-6f);
                 ratio = fminf(fmaxf(ratio, 0.5f), 2.0f);
@@ -333,7 +326,6 @@ __device__ __forceinline__ void tail_masks(const KParams& P, const KFrame& F, in
     }
     // a10 — flicker (ref:630-633); np.float64 factor
     if (P.flags & CRTFX_F_FLICKER) {
-        CRTFX_STAGE_BRANCH();
         v0 = (T)clip01((double)v0 * F.flicker); v1 = (T)clip01((double)v1 * F.flicker); v2 = (T)clip01((double)v2 * F.flicker);
     }
     // a11 — grain (ref:635-647): float32 noise * float32 scale, added in the image dtype

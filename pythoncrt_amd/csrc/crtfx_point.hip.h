@@ -452,18 +452,30 @@ template <uint32_t SF>
 __device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) {
     if constexpr (SF == SF_LEAN_RT) return Pin.flags & ~(uint32_t)CRTFX_F_WARP;
     else if constexpr ((SF & KF_GRADE_RT) != 0) return (SF & ~KF_GRADE_RT) | (Pin.flags & GRADE_RT_MASK);
-    else return SF;
+    else return SF & ~KF_GRADE_LUT;
 }
+// a1 + a4 of one pixel of a lean build from its raw samples: the grade table staged in LDS (KF_GRADE_LUT builds: uint8 samples), or normalise + grade
+template <uint32_t SF, int PIX>
+__device__ __forceinline__ void lean_graded(const KParams& P, const float* glut, const RawRGB& raw, float& r, float& g, float& b) {
+    if constexpr (SF != SF_LEAN_RT && (SF & KF_GRADE_LUT) != 0) { r = glut[raw.r]; g = glut[256 + raw.g]; b = glut[512 + raw.b]; }
+    else if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
+    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
+}
+template <uint32_t SF>
+constexpr int lean_glut_floats() { return (SF != SF_LEAN_RT && (SF & KF_GRADE_LUT) != 0) ? 768 : 1; }
 
 template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, int nseq) {
     __shared__ float lut[2 * LUT_STRIDE];
+    __shared__ float glut[lean_glut_floats<SF>()];
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
     P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
     const bool fastb = (P.flags & CRTFX_F_BLOOM) && (P.flags & CRTFX_F_BLOOM_FAST);      // (compile-time in the folded builds)
-    if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
-        for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    if constexpr (lean_glut_floats<SF>() > 1) { for (int i = threadIdx.x; i < 768; i += blockDim.x) glut[i] = P.grade_lut[i]; }
+    if (((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) || lean_glut_floats<SF>() > 1) {
+        if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT))
+            for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -523,11 +535,7 @@ __global__ __launch_bounds__(1024) void k_point_lean_seq(KParams Pin, KGroup G, 
                 PixMasks M = M0[k];
                 if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
                 float r, g, b;
-                {   // = fetch_graded (no overlay in the lean build)
-                    const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
-                    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
-                    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
-                }
+                lean_graded<SF, PIX>(P, glut, load_raw(PIX, F.in, er[k], eg[k], eb[k]), r, g, b);      // = fetch_graded (no overlay in the lean build)
                 if (fastb) {
                     const char* dsb = reinterpret_cast<const char*>(ds);
                     const F3 p00 = *reinterpret_cast<const F3*>(dsb + o00[k]);
@@ -592,12 +600,19 @@ template <uint32_t SF, int PIX, int BLENDM>
 __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G, int nseq) {
     static_assert((SF == SF_LEAN_RT || (SF & CRTFX_F_BLOOM_FAST) != 0) && CRTFX_POINT_ROWS == 2, "the fused build is the fast-bloom chain, two rows per thread");
     __shared__ float lut[2 * LUT_STRIDE];
+    __shared__ float glut[lean_glut_floats<SF>()];
     extern __shared__ float4 dst[];                // [nseq][34 * (waves + 2)]
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
     P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
     if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
+    }
+    if constexpr (lean_glut_floats<SF>() > 1) {
+        // the grade table feeds the prologue already: staged and made visible first (a barrier of its own; the tile barrier below stays the only
+        // one of the frame loop's)
+        for (int i = threadIdx.x; i < 768; i += blockDim.x) glut[i] = P.grade_lut[i];
+        __syncthreads();
     }
     const int lane = threadIdx.x & 63;
     const int x0 = blockIdx.x * TW;
@@ -628,10 +643,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         ea[3] = (uint32_t)xr1 * 3u; ea[4] = (uint32_t)mx1 * 3u + 1u; ea[5] = (uint32_t)xb1 * 3u + 2u;
     }
     // a1..a4 of one source pixel from its raw samples (= fetch_graded_mapped without an overlay: the lean build has none)
-    auto graded = [&](const RawRGB& raw, float (&v)[3]) {
-        if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { v[0] = P.grade_lut[raw.r]; v[1] = P.grade_lut[256 + raw.g]; v[2] = P.grade_lut[512 + raw.b]; }
-        else { v[0] = norm_px(PIX, raw.r); v[1] = norm_px(PIX, raw.g); v[2] = norm_px(PIX, raw.b); grade(P, v[0], v[1], v[2]); }
-    };
+    auto graded = [&](const RawRGB& raw, float (&v)[3]) { lean_graded<SF, PIX>(P, glut, raw, v[0], v[1], v[2]); };
     // the entry from its four graded pixels: half_body's mean4 form, its operation order (bloom source ref:601-604)
     auto put_entry = [&](int jf, const float (&a)[3], const float (&b)[3], const float (&c)[3], const float (&d)[3]) {
         float o[3];
@@ -736,11 +748,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
                 PixMasks M = M0[k];
                 if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
                 float r, g, b;
-                {   // = fetch_graded (no overlay in the lean build)
-                    const RawRGB raw = load_raw(PIX, F.in, er[k], eg[k], eb[k]);
-                    if (P.grade_lut && (P.flags & CRTFX_F_GAMMA)) { r = P.grade_lut[raw.r]; g = P.grade_lut[256 + raw.g]; b = P.grade_lut[512 + raw.b]; }
-                    else { r = norm_px(PIX, raw.r); g = norm_px(PIX, raw.g); b = norm_px(PIX, raw.b); grade(P, r, g, b); }
-                }
+                lean_graded<SF, PIX>(P, glut, load_raw(PIX, F.in, er[k], eg[k], eb[k]), r, g, b);      // = fetch_graded (no overlay in the lean build)
                 {
                     const float4* tp = tile + t00[k];
                     const float4 p00 = tp[0], p01 = tp[1], p10 = tp[FUSED_TWH], p11 = tp[FUSED_TWH + 1];
