@@ -66,6 +66,8 @@ def test_bench_force_dist_runs_the_n_gt_1_path_over_rccl(config, batch):
     r = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     res = _json_line(r.stdout)
+    # ONE JSON line and nothing else on stdout: RCCL's start-up banner ("RCCL version : ...", five lines) goes to stderr (bench.stdout_to_stderr)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[:600]
     d = res["dist"]
     assert res["n_gpus"] == 1 and res["value"] > 0
     assert d["backend"] == "nccl" and d["backend_version"].startswith("rccl ") and d["world_size_seen"] == 1 and d["forced"] is True
