@@ -1139,12 +1139,16 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             // folded at compile time; every other plane-free gate set (a colour grade, a bloom threshold, stages switched off, flicker, preserve-luma)
             // runs the same kernels with the gate word at run time (SF_LEAN_RT)
             const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
-            const bool folded_gates = gates == SF_FAST || gates == SF_FAST_PIX;
+            // (a bloom threshold does not choose the build: the folded _seq kernels keep that one bit at run time — it acts on the bloom source only;
+            // k_half_group's folded builds do not, so a thresholded source that is a plane comes from the general k_half_group)
+            const bool thr = (gates & CRTFX_F_BLOOM_THR) != 0;
+            const uint32_t gates_nt = gates & ~(uint32_t)CRTFX_F_BLOOM_THR;
+            const bool folded_gates = gates_nt == SF_FAST || gates_nt == SF_FAST_PIX;
             const uint32_t core = gates & ~GRADE_RT_MASK;                    // ... without the purely arithmetic gates
             const bool grade_any = !folded_gates && (core == SF_FAST || core == SF_FAST_PIX);     // the defaults' loads + a grade / threshold / luma / flicker
             // ... of which: uint8 frames whose only extra gates are per-channel grade stages (no saturation) read a1 + a4 from the host's table
             const bool grade_lut = grade_any && c->pix_fmt == CRTFX_PIX_U8 && c->kp.grade_lut != nullptr &&
-                                   (gates & GRADE_RT_MASK & ~(uint32_t)(CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA)) == 0;
+                                   (gates_nt & GRADE_RT_MASK & ~(uint32_t)(CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA)) == 0;
             const bool grade_rt = grade_any && !grade_lut;
             bool lean = lean_gates;
             KGroup kg{};
@@ -1170,7 +1174,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = core == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                const char* gname = folded_gates ? sf_name(gates) : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
+                const char* gname = folded_gates ? sf_name(gates_nt) : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
                                     : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
@@ -1181,8 +1185,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                 if (fastb && !fused) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
                     ProfEv ph(c, 2, g);
-                    plan_note(c->plan.half, "k_half_group<%s,%s>", (lean && folded_gates) ? sf_name(gates) : "runtime", (lean && folded_gates) ? pix_name(c->pix_fmt) : "any");
-                    if (!lean || !folded_gates) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
+                    plan_note(c->plan.half, "k_half_group<%s,%s>", (lean && folded_gates && !thr) ? sf_name(gates) : "runtime", (lean && folded_gates && !thr) ? pix_name(c->pix_fmt) : "any");
+                    if (!lean || !folded_gates || thr) { CRTFX_LAUNCH((k_half_group<SF_RUNTIME, 0>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); }
                     else if (pixelate) { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST_PIX, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                     else { if (f16) { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_F16>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } else { CRTFX_LAUNCH((k_half_group<SF_FAST, CRTFX_PIX_U8>), gh, dim3(256), 0, s, ph.e0, ph.e1, c->kp, kg); } }
                 }

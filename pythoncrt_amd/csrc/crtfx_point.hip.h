@@ -452,7 +452,9 @@ template <uint32_t SF>
 __device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) {
     if constexpr (SF == SF_LEAN_RT) return Pin.flags & ~(uint32_t)CRTFX_F_WARP;
     else if constexpr ((SF & KF_GRADE_RT) != 0) return (SF & ~KF_GRADE_RT) | (Pin.flags & GRADE_RT_MASK);
-    else return SF & ~KF_GRADE_LUT;
+    // the bloom threshold (ref:602-604) only ever acts on the bloom SOURCE — k_half's planes, k_point_fused_seq's prologue — never inside the frame
+    // loop: it stays a run-time bit in every folded build at the price of one scalar branch per half-resolution entry
+    else return (SF & ~KF_GRADE_LUT) | (Pin.flags & CRTFX_F_BLOOM_THR);
 }
 // a1 + a4 of one pixel of a lean build from its raw samples: the grade table staged in LDS (KF_GRADE_LUT builds: uint8 samples), or normalise + grade
 template <uint32_t SF, int PIX>

@@ -548,11 +548,12 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
     assert not any(p.startswith("k_point_fused_seq<") for p in outs["two"][1]), outs["two"][1]
     assert not any(p.startswith(("k_point_fused_seq<", "k_point_lean_seq<")) for p in outs["general"][1]), outs["general"][1]
     if even:
-        # six plane-free, warp-free gate sets x two pixel formats: four keep the defaults' loads (folded) — uint8 frames with a per-channel grade
-        # read it from the host's table (+gradelut: 1 case), a saturation change / bloom threshold / flicker + preserve-luma, and every grade
-        # of half frames, run it at run time (+grade: 3 + 4) — and two switch stages off (the gate word wholly at run time)
+        # six plane-free, warp-free gate sets x two pixel formats: four keep the defaults' loads (folded) — a bloom threshold alone stays on the
+        # fully folded build (that bit acts on the bloom source only and is read at run time there); uint8 frames with a per-channel grade read
+        # it from the host's table (+gradelut: 1 case); a saturation change, flicker + preserve-luma, and every grade of half frames run it at
+        # run time (+grade: 2 + 3) — and two switch stages off (the gate word wholly at run time)
         names = outs["fused"][1]
-        assert sum("+gradelut," in p for p in names) == 1 and sum("+grade," in p for p in names) == 3 + 4, names
+        assert sum("+gradelut," in p for p in names) == 1 and sum("+grade," in p for p in names) == 2 + 3, names
         assert sum(p.startswith("k_point_fused_seq<runtime") for p in names) == 2 * 2, names
     for name in ("two", "fused4", "fused16", "general"):
         assert len(outs[name][0]) == len(outs["fused"][0])
