@@ -255,3 +255,22 @@ def test_pmc_vmem_aggregator_refuses_a_missing_pass(tmp_path):
     import json
     out = json.load(open(tmp_path / "t_vmem.json"))
     assert out == {"crtfx::k_a<1>": {"TA_BUSY": 20.0, "GRBM": 5.0, "TA_STALL": 7.0}}
+
+
+def test_bench_keeps_stdout_to_one_json_line_around_the_rccl_banner():
+    """bench.stdout_to_stderr: whatever a library prints on file descriptor 1 inside the block (RCCL's five-line start-up banner, measured in round 6)
+    lands on stderr; Python's own stdout works again afterwards.  Also: --force-dist is a world-size-1 rehearsal only."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "print('before', flush=True)\n"
+            "with bench.stdout_to_stderr():\n"
+            "    os.write(1, b'RCCL version : banner\\n')\n"
+            "    print('python inside', flush=True)\n"
+            "print('after', flush=True)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert r.stdout.split() == ["before", "after"], r.stdout
+    assert "RCCL version : banner" in r.stderr and "python inside" in r.stderr
+    import bench
+    a = bench.parse_args(["--gpus", "1", "--force-dist", "--config", "4"])
+    assert a.force_dist and a.gpus == 1 and a.config == 4
