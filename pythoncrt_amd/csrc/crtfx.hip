@@ -1144,6 +1144,20 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             const bool thr = (gates & CRTFX_F_BLOOM_THR) != 0;
             const uint32_t gates_nt = gates & ~(uint32_t)CRTFX_F_BLOOM_THR;
             const bool folded_gates = gates_nt == SF_FAST || gates_nt == SF_FAST_PIX;
+            // ... and the defaults with ONE knob turned that the grade table cannot express — a saturation change, preserve-luma, flicker, or one of
+            // grain / vignette / triad / scanlines switched off: folded builds of k_point_fused_seq for uint8 frames (CRTFX_KNOB_SETS below)
+            const char* knob = nullptr;
+            if (!folded_gates && c->pix_fmt == CRTFX_PIX_U8) {
+#define CRTFX_KNOB_SETS(X)                                                                                                                                  \
+    X(| CRTFX_F_SATURATION, "+sat") X(| CRTFX_F_TRIAD_LUMA, "+luma") X(| CRTFX_F_FLICKER, "+flicker") X(& ~(uint32_t)CRTFX_F_NOISE, "-grain")               \
+    X(& ~(uint32_t)(CRTFX_F_VIGNETTE | KF_VIG_UNIT), "-vignette") X(& ~(uint32_t)(CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT), "-triad") X(& ~(uint32_t)CRTFX_F_SCANLINES, "-scanlines")
+#define CRTFX_KNOB_NAME(OP, NAME) if (gates_nt == (uint32_t)(SF_FAST OP) || gates_nt == (uint32_t)(SF_FAST_PIX OP)) knob = NAME;
+                CRTFX_KNOB_SETS(CRTFX_KNOB_NAME)
+#undef CRTFX_KNOB_NAME
+            }
+            // ... and the defaults with the bloom switched off (--bloom-strength 0): a folded k_point_lean_seq (no half-resolution source at all)
+            constexpr uint32_t SF_NOBLOOM = SF_FAST & ~(uint32_t)(CRTFX_F_BLOOM | CRTFX_F_BLOOM_FAST), SF_NOBLOOM_PIX = SF_NOBLOOM | CRTFX_F_PIXELATE;
+            const bool nobloom = !folded_gates && c->pix_fmt == CRTFX_PIX_U8 && (gates_nt == SF_NOBLOOM || gates_nt == SF_NOBLOOM_PIX);
             const uint32_t core = gates & ~GRADE_RT_MASK;                    // ... without the purely arithmetic gates
             const bool grade_any = !folded_gates && (core == SF_FAST || core == SF_FAST_PIX);     // the defaults' loads + a grade / threshold / luma / flicker
             // ... of which: uint8 frames whose only extra gates are per-channel grade stages (no saturation) read a1 + a4 from the host's table
@@ -1173,14 +1187,17 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             }
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
-                const bool pixelate = core == SF_FAST_PIX, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                const char* gname = folded_gates ? sf_name(gates_nt) : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
-                                    : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
+                const bool pixelate = (gates & CRTFX_F_PIXELATE) != 0, f16 = c->pix_fmt == CRTFX_PIX_F16;
                 const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
                 // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
                 // dx / dy tap tables), a block of 4 .. 8 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tiles of the run's
                 // frames: g * 34 * (waves + 2) * 16 bytes of dynamic LDS, 43.5 KB for 8 frames at 8 wavefronts)
                 const bool fused = lean && fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4 && waves <= 8;
+                const bool knob_build = fused && knob != nullptr;      // (the one-knob folded builds exist for the fused kernel only; elsewhere: the run-time forms)
+                char knob_name[40];
+                if (knob_build) snprintf(knob_name, sizeof knob_name, "fast%s%s", pixelate ? "+pixelate" : "", knob);
+                const char* gname = folded_gates ? sf_name(gates_nt) : knob_build ? knob_name : nobloom ? (pixelate ? "fast+pixelate-bloom" : "fast-bloom") : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
+                                    : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
                 const size_t fused_lds = (size_t)g * (TW / 2 + 2) * (waves + 2) * 16;
                 if (fastb && !fused) {
                     dim3 gh((c->kp.hw + 63) / 64, (c->kp.hh + 3) / 4, g);
@@ -1206,7 +1223,15 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); } \
                         else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
-                    if (fused) {
+                    if (knob_build) {
+#define CRTFX_KNOB_LAUNCH(OP, NAME)                                                                                          \
+                        if (gates_nt == (uint32_t)(SF_FAST OP)) CRTFX_FSEQ((uint32_t)(SF_FAST OP), CRTFX_PIX_U8);               \
+                        else if (gates_nt == (uint32_t)(SF_FAST_PIX OP)) CRTFX_FSEQ((uint32_t)(SF_FAST_PIX OP), CRTFX_PIX_U8);  \
+                        else
+                        CRTFX_KNOB_SETS(CRTFX_KNOB_LAUNCH) {}
+#undef CRTFX_KNOB_LAUNCH
+                    }
+                    else if (fused) {
                         if (grade_lut) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_LUT, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_GRADE_LUT, CRTFX_PIX_U8); }
                         else if (grade_rt) {
                             if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_U8); }
@@ -1216,6 +1241,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         else if (pixelate) { if (f16) CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST_PIX, CRTFX_PIX_U8); }
                         else { if (f16) CRTFX_FSEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_FSEQ(SF_FAST, CRTFX_PIX_U8); }
                     }
+                    else if (nobloom) { if (pixelate) CRTFX_SEQ(SF_NOBLOOM_PIX, CRTFX_PIX_U8); else CRTFX_SEQ(SF_NOBLOOM, CRTFX_PIX_U8); }
                     else if (grade_lut) { if (pixelate) CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_LUT, CRTFX_PIX_U8); else CRTFX_SEQ(SF_FAST | KF_GRADE_LUT, CRTFX_PIX_U8); }
                     else if (grade_rt) {
                         if (pixelate) { if (f16) CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST_PIX | KF_GRADE_RT, CRTFX_PIX_U8); }
@@ -1226,6 +1252,7 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                     else { if (f16) CRTFX_SEQ(SF_FAST, CRTFX_PIX_F16); else CRTFX_SEQ(SF_FAST, CRTFX_PIX_U8); }
 #undef CRTFX_FSEQ
 #undef CRTFX_SEQ
+#undef CRTFX_KNOB_SETS
                 } else {
                     dim3 gp((c->W + TW - 1) / TW, (c->H + waves - 1) / waves);
                     const bool one = !(fl & CRTFX_F_PIXELATE) && !fastb;

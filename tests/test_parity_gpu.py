@@ -522,7 +522,10 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
              RenderSettings(brightness=0.05, contrast=1.1), RenderSettings(saturation=1.3, gamma=1.8, temperature=0.2, pixel_size=1),
              RenderSettings(bloom_threshold=0.3, persistence=0.0), RenderSettings(vignette_strength=0.0, noise_strength=0.0),
              RenderSettings(triad_strength=0.0, scanline_strength=0.0, pixel_size=3), RenderSettings(flicker_strength=0.2, flicker_hz=50.0, triad_preserve_luma=True),
-             RenderSettings(vignette_strength=0.0, persistence=0.0, gamma=0.8, warp_strength=0.1)]
+             RenderSettings(vignette_strength=0.0, persistence=0.0, gamma=0.8, warp_strength=0.1),
+             # ... and ONE knob the grade table cannot express: folded builds of their own for uint8 frames (+sat / -grain / -vignette / +flicker here)
+             RenderSettings(saturation=1.2), RenderSettings(noise_strength=0.0), RenderSettings(vignette_strength=0.0, pixel_size=1),
+             RenderSettings(flicker_strength=0.1, flicker_hz=50.0), RenderSettings(bloom_strength=0.0)]
     outs = {}
     for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16}),
                        ("general", {"FORCE_RUNTIME_FLAGS": 1})):      # k_half_group<runtime> + k_point_sel_seq: the kernels every gate set ran on before round 6
@@ -544,17 +547,22 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
         outs[name] = (res, plans)
     effects._tls.engines = {}
     even = h % 2 == 0 and w % 2 == 0
-    assert all(p.startswith("k_point_fused_seq<") for p in outs["fused"][1]) == even, outs["fused"][1]
+    # (the last case has no bloom: nothing to fuse — a folded k_point_lean_seq for uint8 frames, the run-time form for half frames)
+    ok = ("k_point_fused_seq<", "k_point_lean_seq<fast+pixelate-bloom,u8", "k_point_lean_seq<runtime,half")
+    assert all(p.startswith(ok if even else ok[1:]) for p in outs["fused"][1]), outs["fused"][1]
+    assert any(p.startswith("k_point_fused_seq<") for p in outs["fused"][1]) == even
     assert not any(p.startswith("k_point_fused_seq<") for p in outs["two"][1]), outs["two"][1]
     assert not any(p.startswith(("k_point_fused_seq<", "k_point_lean_seq<")) for p in outs["general"][1]), outs["general"][1]
     if even:
-        # six plane-free, warp-free gate sets x two pixel formats: four keep the defaults' loads (folded) — a bloom threshold alone stays on the
+        # (first) six plane-free, warp-free gate sets x two pixel formats: four keep the defaults' loads (folded) — a bloom threshold alone stays on the
         # fully folded build (that bit acts on the bloom source only and is read at run time there); uint8 frames with a per-channel grade read
         # it from the host's table (+gradelut: 1 case); a saturation change, flicker + preserve-luma, and every grade of half frames run it at
         # run time (+grade: 2 + 3) — and two switch stages off (the gate word wholly at run time)
         names = outs["fused"][1]
-        assert sum("+gradelut," in p for p in names) == 1 and sum("+grade," in p for p in names) == 2 + 3, names
-        assert sum(p.startswith("k_point_fused_seq<runtime") for p in names) == 2 * 2, names
+        assert sum("+gradelut," in p for p in names) == 1 and sum("+grade," in p for p in names) == 2 + 3 + 2, names
+        assert sum(p.startswith("k_point_fused_seq<runtime") for p in names) == 2 * 2 + 2, names
+        # the one-knob cases: a folded build for uint8 frames, a run-time form for half frames
+        assert [sum(k in p for p in names) for k in ("+pixelate+sat,u8", "+pixelate-grain,u8", "fast-vignette,u8", "+pixelate+flicker,u8")] == [1, 1, 1, 1], names
     for name in ("two", "fused4", "fused16", "general"):
         assert len(outs[name][0]) == len(outs["fused"][0])
         for k, (x, y) in enumerate(zip(outs["fused"][0], outs[name][0])):

@@ -37,6 +37,8 @@ VARIANTS = [
     ("--glitch 4 px / 0.2", dict(glitch_amp_px=4, glitch_height_frac=0.2)),
     ("--no-fast-bloom (sigma 1.2)", dict(fast_bloom=False)),
     ("--bloom-strength 0", dict(bloom_strength=0.0)),
+    ("--brightness 0.05 --saturation 1.2", dict(brightness=0.05, saturation=1.2)),
+    ("--noise 0 --vignette 0", dict(noise_strength=0.0, vignette_strength=0.0)),
 ]
 
 
