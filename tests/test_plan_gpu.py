@@ -87,3 +87,28 @@ def test_last_plan_through_the_c_abi(monkeypatch):
     assert small.value == full[:11] and small.raw[12:] == b"\xff" * 4                       # n - 1 characters + NUL, nothing past n
     assert lib.crtfx_last_plan(ctx, None, 12) == _lib.E_INVALID and lib.crtfx_last_plan(ctx, small, 0) == _lib.E_INVALID
     assert lib.crtfx_last_plan(None, small, 12) == _lib.E_INVALID
+
+
+def test_plan_of_a_batch_with_a_tail_is_the_full_group(monkeypatch):
+    """crtfx_last_plan after a batch that is not a multiple of the group size (round 6): the record is the FULL-SIZE launch group's, not the
+    shorter tail group's — bench.py's 8192-frame 1080p step is 1638 groups of 5 frames x 168-row blocks + one of 2 x 64, and round 5's
+    committed lines read `group 2, seg_rows 64`."""
+    from pythoncrt_amd import effects
+    from pythoncrt_amd.pipeline import FramePipeline, baseline_config
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    monkeypatch.setattr(effects, "DEBUG_OPTIONS", {})
+    effects._tls.engines = {}
+    rs, h, w = baseline_config(2)
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=1)
+    frames = torch.zeros((7, h, w, 3), dtype=torch.uint8, device=dev)      # 5 + 2
+    pipe.run(frames, first_index=0)
+    plan = pipe.plan()
+    assert plan["group"] == 5 and plan["seg_rows"] == SEG_1080P and plan["warp_frames"] == 5 and plan["group_max"] == 5, plan
+    pipe.run(frames[:2], first_index=0)                                    # a batch that IS only the short group reports that one
+    tail = pipe.plan()
+    assert tail["group"] == 2 and tail["seg_rows"] != SEG_1080P and tail["warp_frames"] == 2, tail
+    del pipe, frames
+    effects._tls.engines = {}
+    torch.cuda.empty_cache()
