@@ -1138,16 +1138,25 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             // scanline plane, an injected grain plane, text overlays).  The gate sets of the reference CLI's defaults have builds with the gate word
             // folded at compile time; every other plane-free gate set (a colour grade, a bloom threshold, stages switched off, flicker, preserve-luma)
             // runs the same kernels with the gate word at run time (SF_LEAN_RT)
-            const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && c->kp.grain <= 1;
+            const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
+            // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): exact 2x decimation (W, H even: no dx / dy tap tables), a block
+            // of 4 .. 8 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tiles of the run's frames)
+            const bool can_fuse = fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4 && waves <= 8;
+            // coarse grain (--grain-size > 1) has one lean build: the defaults' gate set on the fused kernel, uint8 frames (KF_COARSE); anything else
+            // with coarse grain stays on the general kernels
+            const bool coarse = (fl & CRTFX_F_NOISE) && c->kp.grain > 1;
+            const bool coarse_knob = coarse && can_fuse && !c->force_runtime_flags && c->pix_fmt == CRTFX_PIX_U8 &&
+                                     ((gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST || (gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST_PIX);
+            const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && (!coarse || coarse_knob);
             // (a bloom threshold does not choose the build: the folded _seq kernels keep that one bit at run time — it acts on the bloom source only;
             // k_half_group's folded builds do not, so a thresholded source that is a plane comes from the general k_half_group)
             const bool thr = (gates & CRTFX_F_BLOOM_THR) != 0;
             const uint32_t gates_nt = gates & ~(uint32_t)CRTFX_F_BLOOM_THR;
-            const bool folded_gates = gates_nt == SF_FAST || gates_nt == SF_FAST_PIX;
+            const bool folded_gates = (gates_nt == SF_FAST || gates_nt == SF_FAST_PIX) && !coarse;
             // ... and the defaults with ONE knob turned that the grade table cannot express — a saturation change, preserve-luma, flicker, or one of
             // grain / vignette / triad / scanlines switched off: folded builds of k_point_fused_seq for uint8 frames (CRTFX_KNOB_SETS below)
-            const char* knob = nullptr;
-            if (!folded_gates && c->pix_fmt == CRTFX_PIX_U8) {
+            const char* knob = coarse_knob ? "+coarse" : nullptr;
+            if (!folded_gates && !coarse && c->pix_fmt == CRTFX_PIX_U8) {
 #define CRTFX_KNOB_SETS(X)                                                                                                                                  \
     X(| CRTFX_F_SATURATION, "+sat") X(| CRTFX_F_TRIAD_LUMA, "+luma") X(| CRTFX_F_FLICKER, "+flicker") X(& ~(uint32_t)CRTFX_F_NOISE, "-grain")               \
     X(& ~(uint32_t)(CRTFX_F_VIGNETTE | KF_VIG_UNIT), "-vignette") X(& ~(uint32_t)(CRTFX_F_TRIAD | CRTFX_F_TRIAD_LUT), "-triad") X(& ~(uint32_t)CRTFX_F_SCANLINES, "-scanlines")
@@ -1188,11 +1197,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = (gates & CRTFX_F_PIXELATE) != 0, f16 = c->pix_fmt == CRTFX_PIX_F16;
-                const int waves = c->point_tiles > 0 ? c->point_tiles : 8;
-                // the fast-bloom source formed inside the pointwise kernel (k_point_fused_seq): lean frames, exact 2x decimation (W, H even: no
-                // dx / dy tap tables), a block of 4 .. 8 wavefronts (its first 34 x (waves + 2) threads form the half-resolution tiles of the run's
-                // frames: g * 34 * (waves + 2) * 16 bytes of dynamic LDS, 43.5 KB for 8 frames at 8 wavefronts)
-                const bool fused = lean && fastb && !c->no_fused_half && !c->kp.dx_ofs && waves >= 4 && waves <= 8;
+                // (g * 34 * (waves + 2) * 16 bytes of dynamic LDS for the tiles: 43.5 KB for 8 frames at 8 wavefronts)
+                const bool fused = lean && can_fuse;
                 const bool knob_build = fused && knob != nullptr;      // (the one-knob folded builds exist for the fused kernel only; elsewhere: the run-time forms)
                 char knob_name[40];
                 if (knob_build) snprintf(knob_name, sizeof knob_name, "fast%s%s", pixelate ? "+pixelate" : "", knob);
@@ -1223,7 +1229,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); } \
                         else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
-                    if (knob_build) {
+                    if (knob_build && coarse_knob) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_COARSE, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_COARSE, CRTFX_PIX_U8); }
+                    else if (knob_build) {
 #define CRTFX_KNOB_LAUNCH(OP, NAME)                                                                                          \
                         if (gates_nt == (uint32_t)(SF_FAST OP)) CRTFX_FSEQ((uint32_t)(SF_FAST OP), CRTFX_PIX_U8);               \
                         else if (gates_nt == (uint32_t)(SF_FAST_PIX OP)) CRTFX_FSEQ((uint32_t)(SF_FAST_PIX OP), CRTFX_PIX_U8);  \

@@ -454,8 +454,10 @@ __device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) {
     else if constexpr ((SF & KF_GRADE_RT) != 0) return (SF & ~KF_GRADE_RT) | (Pin.flags & GRADE_RT_MASK);
     // the bloom threshold (ref:602-604) only ever acts on the bloom SOURCE — k_half's planes, k_point_fused_seq's prologue — never inside the frame
     // loop: it stays a run-time bit in every folded build at the price of one scalar branch per half-resolution entry
-    else return (SF & ~KF_GRADE_LUT) | (Pin.flags & CRTFX_F_BLOOM_THR);
+    else return (SF & ~(KF_GRADE_LUT | KF_COARSE)) | (Pin.flags & CRTFX_F_BLOOM_THR);
 }
+template <uint32_t SF>
+constexpr bool lean_coarse() { return SF != SF_LEAN_RT && (SF & KF_COARSE) != 0; }
 // a1 + a4 of one pixel of a lean build from its raw samples: the grade table staged in LDS (KF_GRADE_LUT builds: uint8 samples), or normalise + grade
 template <uint32_t SF, int PIX>
 __device__ __forceinline__ void lean_graded(const KParams& P, const float* glut, const RawRGB& raw, float& r, float& g, float& b) {
@@ -606,7 +608,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
     extern __shared__ float4 dst[];                // [nseq][34 * (waves + 2)]
     constexpr int ROWS = CRTFX_POINT_ROWS;
     KParams P = Pin;
-    P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr; P.grain = 1;
+    P.flags = lean_flags<SF>(Pin); P.pix = PIX; P.triad_full = nullptr; P.vig_full = nullptr;
+    if constexpr (!lean_coarse<SF>()) P.grain = 1;
     if ((P.flags & CRTFX_F_TRIAD) && (P.flags & CRTFX_F_TRIAD_LUT)) {
         for (int i = threadIdx.x; i < LUT_N; i += blockDim.x) { lut[i] = P.lut_g[i]; lut[LUT_STRIDE + i] = P.lut_inv[i]; }
     }
@@ -705,6 +708,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
     float a0[ROWS], a1[ROWS], b0[ROWS], b1[ROWS];
     F3 st[ROWS];
     PixMasks M0[ROWS];
+    int gsx[ROWS], gsy[ROWS];                                 // coarse grain (KF_COARSE builds): the pixel's taps into the coarse plane of normals, frame-invariant
+    float ga1[ROWS], gb1[ROWS];
     const float* state_in = G.o[0].state_in ? G.o[0].state_in : G.o[0].state;
 #pragma unroll
     for (int k = 0; k < ROWS; ++k) {
@@ -723,6 +728,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
             const int lx = min(max(sx - i0, 0), FUSED_TWH - 2), ly = min(max(sy - j0, 0), thh - 2);
             t00[k] = (uint32_t)(ly * FUSED_TWH + lx);
         }
+        if constexpr (lean_coarse<SF>()) { gsx[k] = P.gx_ofs[x]; gsy[k] = P.gy_ofs[y]; ga1[k] = P.gx_a[x]; gb1[k] = P.gy_a[y]; }
+        else { gsx[k] = gsy[k] = 0; ga1[k] = gb1[k] = 0.0f; }
         {   // = fetch_raw's addressing (ref:573-583), frame-invariant
             int xs = x, ys = y;
             if (P.flags & CRTFX_F_PIXELATE) { xs = P.xmap[x]; ys = P.ymap[y]; }
@@ -749,6 +756,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
                 const int y = yr[k];
                 PixMasks M = M0[k];
                 if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
+                if constexpr (lean_coarse<SF>()) { M.z = coarse_grain(P, F, gsx[k], gsy[k], ga1[k], gb1[k]); M.has_z = 1; }      // = k_point_sel_seq's
                 float r, g, b;
                 lean_graded<SF, PIX>(P, glut, load_raw(PIX, F.in, er[k], eg[k], eb[k]), r, g, b);      // = fetch_graded (no overlay in the lean build)
                 {

@@ -525,7 +525,8 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
              RenderSettings(vignette_strength=0.0, persistence=0.0, gamma=0.8, warp_strength=0.1),
              # ... and ONE knob the grade table cannot express: folded builds of their own for uint8 frames (+sat / -grain / -vignette / +flicker here)
              RenderSettings(saturation=1.2), RenderSettings(noise_strength=0.0), RenderSettings(vignette_strength=0.0, pixel_size=1),
-             RenderSettings(flicker_strength=0.1, flicker_hz=50.0), RenderSettings(bloom_strength=0.0)]
+             RenderSettings(flicker_strength=0.1, flicker_hz=50.0), RenderSettings(grain_size=2), RenderSettings(grain_size=3, pixel_size=1, persistence=0.0),
+             RenderSettings(bloom_strength=0.0)]
     outs = {}
     for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16}),
                        ("general", {"FORCE_RUNTIME_FLAGS": 1})):      # k_half_group<runtime> + k_point_sel_seq: the kernels every gate set ran on before round 6
@@ -548,8 +549,9 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
     effects._tls.engines = {}
     even = h % 2 == 0 and w % 2 == 0
     # (the last case has no bloom: nothing to fuse — a folded k_point_lean_seq for uint8 frames, the run-time form for half frames)
-    ok = ("k_point_fused_seq<", "k_point_lean_seq<fast+pixelate-bloom,u8", "k_point_lean_seq<runtime,half")
-    assert all(p.startswith(ok if even else ok[1:]) for p in outs["fused"][1]), outs["fused"][1]
+    # (coarse grain: a folded build of the fused kernel for uint8 frames; half frames stay on the general k_point_sel_seq)
+    ok = ("k_point_fused_seq<", "k_point_lean_seq<fast+pixelate-bloom,u8", "k_point_lean_seq<runtime,half", "k_point_sel_seq<half")
+    assert not even or all(p.startswith(ok) for p in outs["fused"][1]), outs["fused"][1]
     assert any(p.startswith("k_point_fused_seq<") for p in outs["fused"][1]) == even
     assert not any(p.startswith("k_point_fused_seq<") for p in outs["two"][1]), outs["two"][1]
     assert not any(p.startswith(("k_point_fused_seq<", "k_point_lean_seq<")) for p in outs["general"][1]), outs["general"][1]
@@ -563,6 +565,7 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
         assert sum(p.startswith("k_point_fused_seq<runtime") for p in names) == 2 * 2 + 2, names
         # the one-knob cases: a folded build for uint8 frames, a run-time form for half frames
         assert [sum(k in p for p in names) for k in ("+pixelate+sat,u8", "+pixelate-grain,u8", "fast-vignette,u8", "+pixelate+flicker,u8")] == [1, 1, 1, 1], names
+        assert [sum(k in p for p in names) for k in ("fast+pixelate+coarse,u8,render", "fast+coarse,u8,none")] == [1, 1], names
     for name in ("two", "fused4", "fused16", "general"):
         assert len(outs[name][0]) == len(outs["fused"][0])
         for k, (x, y) in enumerate(zip(outs["fused"][0], outs[name][0])):
