@@ -274,3 +274,43 @@ def test_bench_keeps_stdout_to_one_json_line_around_the_rccl_banner():
     import bench
     a = bench.parse_args(["--gpus", "1", "--force-dist", "--config", "4"])
     assert a.force_dist and a.gpus == 1 and a.config == 4
+
+
+def _synthetic_line(n, value, clk=2250.0, pw=1320.0, own=None, chain=0.0194, sched=None, workload="BASELINE configs[3]: 1920x1080 chain, persistence 0.5, u8 in/out"):
+    own = own or [value / n] * n
+    return {"metric": "1080p frames/sec (whole node)", "value": value, "n_gpus": n, "config": {"workload": workload},
+            "dist": {"world_size_seen": n, "hop_schedule": "synchronous" if sched else None,
+                     "per_rank": [{"rank": r, "frames_per_s_own_clock": own[r], "chain_ms_per_frame": chain,
+                                   "gpu": {"sclk_mhz_mean": clk if not isinstance(clk, list) else clk[r], "power_w_mean": pw}} for r in range(n)]},
+            **({"shard_schedule": sched} if sched else {})}
+
+
+def test_scale_report_reads_the_cause_from_the_lines(tmp_path, capsys):
+    """tools/scale_report.py — the 8-GPU run sheet as a program: from bench.py lines at N = 1 and N = 8 it states the speed-up
+    against north_star's >= 7x and, under target, the cause the per-rank fields point at: a node power cap (clocks below the 1-GPU line's), the
+    persistence hop (hop + fix-up share of a round), a straggling host (one rank slow on its own clock with equal kernel time)."""
+    import json
+    import scale_report as sr
+    base = _synthetic_line(1, 51600.0)
+    sched_ok = {"scan_us": 79000.0, "hop_stall_us": 160.0, "fixup_us": 150.0, "hop_plus_fixup_share": 0.0039}
+    cases = {
+        "healthy": (_synthetic_line(8, 8 * 51600.0 * 0.97, sched=sched_ok), 0, ["7.76x", "MET"], ["->"]),
+        "capped": (_synthetic_line(8, 8 * 51600.0 * 0.80, clk=1850.0, pw=1050.0, sched=sched_ok), 1, ["NOT MET", "power / thermal cap"], []),
+        "hop": (_synthetic_line(8, 8 * 51600.0 * 0.84, sched={"scan_us": 79000.0, "hop_stall_us": 14000.0, "fixup_us": 150.0, "hop_plus_fixup_share": 0.152}), 1,
+                ["NOT MET", "CRTFX_SHARD_OVERLAP=1"], ["power / thermal cap"]),
+        "straggler": (_synthetic_line(8, 8 * 43000.0, own=[51000.0] * 7 + [43000.0], sched=sched_ok), 1, ["NOT MET", "straggler"], ["power / thermal cap"]),
+    }
+    for name, (line, rc, must, must_not) in cases.items():
+        p1, p8 = tmp_path / f"{name}_1.json", tmp_path / f"{name}_8.json"
+        p1.write_text("RCCL version : banner line\n" + json.dumps(base) + "\n")          # other lines around the JSON line are ignored
+        p8.write_text(json.dumps({"rc": 0, "parsed": line}))                              # ... and a driver record with the line under "parsed" is accepted
+        assert sr.main(["scale_report.py", str(p8), str(p1)]) == rc, name
+        out = capsys.readouterr().out
+        for m in must:
+            assert m in out, (name, m, out)
+        for m in must_not:
+            assert m not in out, (name, m, out)
+    # the committed rehearsal (five gloo ranks on ONE GPU) parses: every field the run sheet names is in the line
+    reh = json.load(open(os.path.join(ROOT, "profiles", "r06_five_rank_rehearsal.json")))
+    verdict, text = sr.diagnose(json.load(open(os.path.join(ROOT, "profiles", "r06_z_c4_bench.json"))), reh["config4"])
+    assert verdict == "UNDER TARGET" and any("persistence hop (overlapped)" in t for t in text) and any("shader clock per rank" in t for t in text)
