@@ -197,3 +197,52 @@ def test_records_built_ahead_of_their_launches(dev, speed):
         got, _ = pipe.run(frames, first_index=f, records=recs)
         assert torch.equal(got, exp), f
     del junk, big
+
+
+CLI_PARAM_KEYS = PARAM_KEYS + ("brightness", "contrast", "gamma", "saturation", "temperature", "flicker_strength", "flicker_hz", "grain_size")
+
+
+@pytest.mark.parametrize("name,kw,build", [
+    ("defaults", {}, "k_point_fused_seq<fast+pixelate,u8,render>"),
+    ("grade table", dict(brightness=0.05, contrast=1.1, gamma=1.2, temperature=-0.2), "k_point_fused_seq<fast+pixelate+gradelut,u8,render>"),
+    ("saturation", dict(saturation=1.3), "k_point_fused_seq<fast+pixelate+sat,u8,render>"),
+    ("coarse grain", dict(grain_size=2), "k_point_fused_seq<fast+pixelate+coarse,u8,render>"),
+    ("several knobs", dict(saturation=1.2, bloom_threshold=0.3, flicker_strength=0.2, flicker_hz=9.0, pixel_size=1), "k_point_fused_seq<fast+grade,u8,render>"),
+    ("stages off", dict(vignette_strength=0.0, noise_strength=0.0, persistence=0.0), "k_point_fused_seq<runtime,u8,none>"),
+])
+def test_1080p_cli_chain_on_the_fused_kernel_against_oracle(dev, name, kw, build):
+    """The chain `python -m pythoncrt_amd.cli` runs with no flags (ref:1160-1206: fast bloom, pixel size 2, persistence 0.2) and with one or several
+    knobs turned, at 1080p through crtfx_process_batch — round 6's k_point_fused_seq in each of its gate forms, its half-resolution tiles, prologue
+    and a run of eight frames at the size bench.py --config 0 measures — against the oracle's in-order render of the same ten frames, the grain the
+    kernels drew exported for it.  Frame 0 (no blend yet) bit-exact; the blended frames <= 1 LSB on < 0.1 % of the samples."""
+    import dataclasses
+    from pythoncrt_amd.pipeline import FramePipeline, RenderSettings
+    rs = dataclasses.replace(RenderSettings(), **kw)
+    h, w, n, first, seed = 1080, 1920, 10, 5, 777
+    frames = np.stack([make_frame(h, w, seed=900 + i, kind="grad" if i % 2 else "noise") for i in range(n)])
+    pipe = FramePipeline(dev, h, w, rs, fps=30.0, noise_seed=seed)
+    out, state = pipe.run(torch.from_numpy(frames).to(dev), first_index=first)
+    assert pipe.plan().get("point") == build, pipe.plan()
+    planes = None
+    if rs.noise_strength > 0.0:
+        g = rs.grain_size
+        if g > 1:
+            from pythoncrt_amd.effects import Engine
+            small = Engine(dev, max(1, h // g), max(1, w // g), 0)
+            planes = []
+            for i in range(n):
+                p = torch.empty((small.h, small.w), dtype=torch.float32, device=dev)
+                assert small.lib.crtfx_noise_plane(small.ctx, seed, first + i, p.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+                planes.append(p.cpu().numpy())
+        else:
+            planes = _export_planes(pipe, seed, first, n, h, w)
+    params = {k: getattr(rs, k) for k in CLI_PARAM_KEYS}
+    exp, exp_state = orc.process_frames(list(frames), params, 30.0, rs.scanline_speed_px_s, rs.persistence, rs.triad_strength,
+                                        rs.triad_softness, rs.vignette_strength, noise_planes=planes, first_index=first)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], exp[0]), name
+    for i in range(n):
+        d = np.abs(got[i].astype(np.int16) - exp[i].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-3, (name, i, int(d.max()), float((d != 0).mean()))
+    if state is not None:
+        assert np.abs(state.cpu().numpy().astype(np.float64) - exp_state).max() <= 1e-6, name
