@@ -1148,6 +1148,11 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
             const bool coarse_knob = coarse && can_fuse && !c->force_runtime_flags && c->pix_fmt == CRTFX_PIX_U8 &&
                                      ((gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST || (gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST_PIX);
             const bool lean_gates = !c->force_runtime_flags && !c->kp.triad_full && !c->kp.vig_full && (!coarse || coarse_knob);
+            // a 2-D scanline plane per frame (--scanline-angle / --scanline-thickness) has one lean build too: the defaults' gate set, uint8 frames, every
+            // frame of the group with a plane (KF_SCANPLANE)
+            const bool scan_ok = can_fuse && !coarse && c->pix_fmt == CRTFX_PIX_U8 &&
+                                 ((gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST || (gates & ~(uint32_t)CRTFX_F_BLOOM_THR) == SF_FAST_PIX);
+            int nplane = 0;
             // (a bloom threshold does not choose the build: the folded _seq kernels keep that one bit at run time — it acts on the bloom source only;
             // k_half_group's folded builds do not, so a thresholded source that is a plane comes from the general k_half_group)
             const bool thr = (gates & CRTFX_F_BLOOM_THR) != 0;
@@ -1192,17 +1197,20 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                     k1.pre = c->pre + (size_t)g * frame_elems; k1.pix = c->pix_fmt; k1.dbg = c->dbg;
                     kg.o[g] = k1;
                 } else kg.o[g] = ko;
-                if (kg.f[g].scan_plane || kg.f[g].noise_plane || kg.f[g].overlay_before || kg.o[g].overlay_after) lean = false;
+                if (kg.f[g].noise_plane || kg.f[g].overlay_before || kg.o[g].overlay_after) lean = false;
+                if (kg.f[g].scan_plane) ++nplane;
             }
+            const bool scan_knob = nplane > 0 && nplane == g && scan_ok && lean;
+            if (nplane > 0 && !scan_knob) lean = false;
             if (g >= 2) {
                 c->prof_this = c->prof && (c->prof_frame++ % (unsigned)c->prof_stride == 0);
                 const bool pixelate = (gates & CRTFX_F_PIXELATE) != 0, f16 = c->pix_fmt == CRTFX_PIX_F16;
                 // (g * 34 * (waves + 2) * 16 bytes of dynamic LDS for the tiles: 43.5 KB for 8 frames at 8 wavefronts)
                 const bool fused = lean && can_fuse;
-                const bool knob_build = fused && knob != nullptr;      // (the one-knob folded builds exist for the fused kernel only; elsewhere: the run-time forms)
+                const bool knob_build = fused && (knob != nullptr || scan_knob);      // (the one-knob folded builds exist for the fused kernel only; elsewhere: the run-time forms)
                 char knob_name[40];
-                if (knob_build) snprintf(knob_name, sizeof knob_name, "fast%s%s", pixelate ? "+pixelate" : "", knob);
-                const char* gname = folded_gates ? sf_name(gates_nt) : knob_build ? knob_name : nobloom ? (pixelate ? "fast+pixelate-bloom" : "fast-bloom") : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
+                if (knob_build) snprintf(knob_name, sizeof knob_name, "fast%s%s", pixelate ? "+pixelate" : "", scan_knob ? "+scan2d" : knob);
+                const char* gname = (folded_gates && !scan_knob) ? sf_name(gates_nt) : knob_build ? knob_name : nobloom ? (pixelate ? "fast+pixelate-bloom" : "fast-bloom") : grade_lut ? (pixelate ? "fast+pixelate+gradelut" : "fast+gradelut")
                                     : grade_rt ? (pixelate ? "fast+pixelate+grade" : "fast+grade") : "runtime";
                 const size_t fused_lds = (size_t)g * (TW / 2 + 2) * (waves + 2) * 16;
                 if (fastb && !fused) {
@@ -1229,7 +1237,8 @@ int crtfx_process_batch(crtfx_ctx* c, const void* frames_base, size_t frame_stri
                         if (kg.o[0].blend == CRTFX_BLEND_RENDER) { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_RENDER>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); } \
                         else { CRTFX_LAUNCH((k_point_fused_seq<SFV, PIXV, CRTFX_BLEND_NONE>), gp, dim3(64 * waves), fused_lds, s, pe.e0, pe.e1, c->kp, kg, g); }                     \
                     } while (0)
-                    if (knob_build && coarse_knob) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_COARSE, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_COARSE, CRTFX_PIX_U8); }
+                    if (knob_build && scan_knob) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_SCANPLANE, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_SCANPLANE, CRTFX_PIX_U8); }
+                    else if (knob_build && coarse_knob) { if (pixelate) CRTFX_FSEQ(SF_FAST_PIX | KF_COARSE, CRTFX_PIX_U8); else CRTFX_FSEQ(SF_FAST | KF_COARSE, CRTFX_PIX_U8); }
                     else if (knob_build) {
 #define CRTFX_KNOB_LAUNCH(OP, NAME)                                                                                          \
                         if (gates_nt == (uint32_t)(SF_FAST OP)) CRTFX_FSEQ((uint32_t)(SF_FAST OP), CRTFX_PIX_U8);               \

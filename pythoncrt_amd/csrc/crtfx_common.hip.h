@@ -115,6 +115,9 @@ constexpr uint32_t KF_GRADE_LUT = 1u << 29;
 // ... and coarse grain (--grain-size > 1, ref:637-642: N(0,1) drawn at (H // g) x (W // g), bilinearly upsampled): the pixel's sample formed from four
 // hashed normals with frame-invariant taps, as k_point_sel_seq does, in a folded build of k_point_fused_seq: SF = SF_FAST[_PIX] | KF_COARSE
 constexpr uint32_t KF_COARSE = 1u << 28;
+// ... and slanted / shaped scanlines (--scanline-angle, --scanline-thickness; make_scanline_mask_2d ref:308-328): the gain is a per-pixel, per-frame
+// plane (crtfx_frame.scan_plane_dev) instead of a row table: one more load per pixel, SF = SF_FAST[_PIX] | KF_SCANPLANE
+constexpr uint32_t KF_SCANPLANE = 1u << 27;
 constexpr uint32_t GRADE_RT_MASK = CRTFX_F_SATURATION | CRTFX_F_TEMPERATURE | CRTFX_F_BRIGHTCON | CRTFX_F_GAMMA | CRTFX_F_BLOOM_THR | CRTFX_F_TRIAD_LUMA | CRTFX_F_FLICKER;
 
 constexpr int TW = 64;            // strip width in pixels (one wavefront of columns)

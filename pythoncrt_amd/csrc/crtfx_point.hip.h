@@ -454,8 +454,10 @@ __device__ __forceinline__ uint32_t lean_flags(const KParams& Pin) {
     else if constexpr ((SF & KF_GRADE_RT) != 0) return (SF & ~KF_GRADE_RT) | (Pin.flags & GRADE_RT_MASK);
     // the bloom threshold (ref:602-604) only ever acts on the bloom SOURCE — k_half's planes, k_point_fused_seq's prologue — never inside the frame
     // loop: it stays a run-time bit in every folded build at the price of one scalar branch per half-resolution entry
-    else return (SF & ~(KF_GRADE_LUT | KF_COARSE)) | (Pin.flags & CRTFX_F_BLOOM_THR);
+    else return (SF & ~(KF_GRADE_LUT | KF_COARSE | KF_SCANPLANE)) | (Pin.flags & CRTFX_F_BLOOM_THR);
 }
+template <uint32_t SF>
+constexpr bool lean_scanplane() { return SF != SF_LEAN_RT && (SF & KF_SCANPLANE) != 0; }
 template <uint32_t SF>
 constexpr bool lean_coarse() { return SF != SF_LEAN_RT && (SF & KF_COARSE) != 0; }
 // a1 + a4 of one pixel of a lean build from its raw samples: the grade table staged in LDS (KF_GRADE_LUT builds: uint8 samples), or normalise + grade
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         const int y = yr[k] = min(ybase + k * waves, P.H - 1);     // a row past the bottom redoes the last one; its stores are skipped
         {
             KFrame F0 = G.f[0];
-            F0.scan_plane = nullptr;
+            if constexpr (!lean_scanplane<SF>()) F0.scan_plane = nullptr;      // (a plane build's frames carry no row table: the gain of frame 0 is read here, and again below)
             M0[k] = load_masks(P, F0, y, x);
         }
         {
@@ -745,7 +747,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
         using T = decltype(tzero);
         for (int jf = 0; jf < nseq; ++jf) {
             KFrame F = G.f[jf];                        // wave-uniform index: scalar loads
-            F.scan_plane = nullptr; F.noise_plane = nullptr; F.overlay_before = nullptr;
+            if constexpr (!lean_scanplane<SF>()) F.scan_plane = nullptr;
+            F.noise_plane = nullptr; F.overlay_before = nullptr;
             KOut O = G.o[jf];
             O.pix = PIX;
             const bool keep_state = jf == nseq - 1 || G.o[jf + 1].state != O.state;
@@ -755,7 +758,8 @@ __global__ __launch_bounds__(1024) void k_point_fused_seq(KParams Pin, KGroup G,
             for (int k = 0; k < ROWS; ++k) {
                 const int y = yr[k];
                 PixMasks M = M0[k];
-                if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
+                if constexpr (lean_scanplane<SF>()) M.sl = F.scan_plane[(uint32_t)y * (uint32_t)P.W + (uint32_t)x];
+                else if (P.flags & CRTFX_F_SCANLINES) M.sl = F.scan_row[y];
                 if constexpr (lean_coarse<SF>()) { M.z = coarse_grain(P, F, gsx[k], gsy[k], ga1[k], gb1[k]); M.has_z = 1; }      // = k_point_sel_seq's
                 float r, g, b;
                 lean_graded<SF, PIX>(P, glut, load_raw(PIX, F.in, er[k], eg[k], eb[k]), r, g, b);      // = fetch_graded (no overlay in the lean build)

@@ -526,6 +526,7 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
              # ... and ONE knob the grade table cannot express: folded builds of their own for uint8 frames (+sat / -grain / -vignette / +flicker here)
              RenderSettings(saturation=1.2), RenderSettings(noise_strength=0.0), RenderSettings(vignette_strength=0.0, pixel_size=1),
              RenderSettings(flicker_strength=0.1, flicker_hz=50.0), RenderSettings(grain_size=2), RenderSettings(grain_size=3, pixel_size=1, persistence=0.0),
+             RenderSettings(scanline_angle=10.0), RenderSettings(scanline_thickness=2.0, scanline_angle=-4.0, pixel_size=1, persistence=0.0),      # a 2-D scanline plane per frame
              RenderSettings(bloom_strength=0.0)]
     outs = {}
     for name, opts in (("fused", {}), ("two", {"NO_FUSED_HALF": 1}), ("fused4", {"POINT_TILES": 4}), ("fused16", {"POINT_TILES": 16}),
@@ -566,6 +567,7 @@ def test_fused_fast_bloom_kernel_equals_the_two_launch_path(pc, hw, monkeypatch)
         # the one-knob cases: a folded build for uint8 frames, a run-time form for half frames
         assert [sum(k in p for p in names) for k in ("+pixelate+sat,u8", "+pixelate-grain,u8", "fast-vignette,u8", "+pixelate+flicker,u8")] == [1, 1, 1, 1], names
         assert [sum(k in p for p in names) for k in ("fast+pixelate+coarse,u8,render", "fast+coarse,u8,none")] == [1, 1], names
+        assert [sum(k in p for p in names) for k in ("fast+pixelate+scan2d,u8,render", "fast+scan2d,u8,none")] == [1, 1], names
     for name in ("two", "fused4", "fused16", "general"):
         assert len(outs[name][0]) == len(outs["fused"][0])
         for k, (x, y) in enumerate(zip(outs["fused"][0], outs[name][0])):

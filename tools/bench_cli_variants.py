@@ -33,6 +33,7 @@ VARIANTS = [
     ("--grain-size 2", dict(grain_size=2)),
     ("--flicker 0.1 @ 50 Hz", dict(flicker_strength=0.1, flicker_hz=50.0)),
     ("--scanline-angle 10", dict(scanline_angle=10.0)),
+    ("--scanline-thickness 2", dict(scanline_thickness=2.0)),
     ("--warp-strength 0.15", dict(warp_strength=0.15)),
     ("--glitch 4 px / 0.2", dict(glitch_amp_px=4, glitch_height_frac=0.2)),
     ("--no-fast-bloom (sigma 1.2)", dict(fast_bloom=False)),
