@@ -262,3 +262,15 @@ def test_half_quotient_constants_exact():
                 assert p == 0 and np.signbit(p) == np.signbit(f) and np.signbit(want) == np.signbit(f)      # (+-0) * C_HI + (+-0): the sign survives only because C_LO > 0
             else:
                 assert np.isinf(p) and np.signbit(p) == np.signbit(f) and want == f                           # inf * C_HI + inf (same sign): inf, not NaN
+
+
+def test_option_ids_match_the_header():
+    """effects._OPTION_IDS (the names bench.py --opt and the tests use) against the CRTFX_OPT_* enumerators of include/crtfx.h: one table cannot drift
+    from the other (round 6 added NO_FUSED_HALF = 16)."""
+    import os
+    import re
+    from pythoncrt_amd import effects
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "crtfx.h")).read()
+    enum = {m.group(1): int(m.group(2)) for m in re.finditer(r"CRTFX_OPT_([A-Z_]+)\s*=\s*(\d+)", text)}
+    assert enum and enum == effects._OPTION_IDS, (sorted(set(enum.items()) ^ set(effects._OPTION_IDS.items())))
